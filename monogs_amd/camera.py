@@ -1,0 +1,136 @@
+"""Camera-matrix and pose helpers on the caller's side of the rasteriser boundary.
+
+These mirror the conventions of the reference's helpers so that the tensors handed to
+``GaussianRasterizationSettings`` are the same ones MonoGS builds:
+
+* ``world2view`` / ``projection_matrix`` / ``full_proj_transform``:
+  /root/reference/gaussian_splatting/utils/graphics_utils.py:33-42,68-89 and
+  /root/reference/utils/camera_utils.py:39-49,171-178,224-231.  All three matrices are handed to
+  the kernels TRANSPOSED (row-vector convention): flat element ``4*j+i`` of the tensor is maths
+  element (i, j).
+* ``se3_exp`` / ``retract_pose``: /root/reference/utils/pose_utils.py:25-93 --
+  ``T_cw <- exp([rho; theta]^) @ T_cw``; this is the convention dL/dtheta and dL/drho of the
+  rasteriser are defined against.
+
+They are checked against values produced by the reference's own functions in
+tests/test_golden.py (fixtures tests/golden/camera_pose.npz).
+"""
+from __future__ import annotations
+
+import math
+from typing import NamedTuple
+
+import torch
+
+ZNEAR = 0.01   # /root/reference/utils/camera_utils.py:41-42
+ZFAR = 100.0
+
+
+def world2view(R: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
+    """4x4 world-to-camera matrix [[R, t], [0, 1]]; R, t are already world->camera."""
+    M = torch.zeros(4, 4, dtype=torch.float32, device=R.device)
+    M[:3, :3] = R
+    M[:3, 3] = t
+    M[3, 3] = 1.0
+    return M
+
+
+def projection_matrix(fx, fy, cx, cy, W, H, znear=ZNEAR, zfar=ZFAR, device="cpu") -> torch.Tensor:
+    """Off-centre pinhole projection, z in [znear, zfar] -> [0, 1], w = z (un-transposed)."""
+    fx_t = torch.as_tensor([float(fx)], dtype=torch.float32, device=device)
+    fy_t = torch.as_tensor([float(fy)], dtype=torch.float32, device=device)
+    # frustum edges on the near plane, computed in the same float32 steps as the reference
+    l_ = znear / fx_t * (((2 * cx - W) / W - 1.0) * W / 2.0)
+    r_ = znear / fx_t * (((2 * cx - W) / W + 1.0) * W / 2.0)
+    t_ = znear / fy_t * (((2 * cy - H) / H + 1.0) * H / 2.0)
+    b_ = znear / fy_t * (((2 * cy - H) / H - 1.0) * H / 2.0)
+    Pm = torch.zeros(4, 4, dtype=torch.float32, device=device)
+    Pm[0, 0] = 2.0 * znear / (r_ - l_)
+    Pm[1, 1] = 2.0 * znear / (t_ - b_)
+    Pm[0, 2] = (r_ + l_) / (r_ - l_)
+    Pm[1, 2] = (t_ + b_) / (t_ - b_)
+    Pm[3, 2] = 1.0
+    Pm[2, 2] = zfar / (zfar - znear)
+    Pm[2, 3] = -(zfar * znear) / (zfar - znear)
+    return Pm
+
+
+def _skew(v: torch.Tensor) -> torch.Tensor:
+    S = torch.zeros(3, 3, dtype=v.dtype, device=v.device)
+    S[0, 1], S[0, 2] = -v[2], v[1]
+    S[1, 0], S[1, 2] = v[2], -v[0]
+    S[2, 0], S[2, 1] = -v[1], v[0]
+    return S
+
+
+def so3_exp(theta: torch.Tensor) -> torch.Tensor:
+    K = _skew(theta)
+    K2 = K @ K
+    a = torch.norm(theta)
+    eye = torch.eye(3, dtype=theta.dtype, device=theta.device)
+    if a < 1e-5:
+        return eye + K + 0.5 * K2
+    return eye + (torch.sin(a) / a) * K + ((1 - torch.cos(a)) / (a ** 2)) * K2
+
+
+def so3_left_jacobian(theta: torch.Tensor) -> torch.Tensor:
+    K = _skew(theta)
+    K2 = K @ K
+    a = torch.norm(theta)
+    eye = torch.eye(3, dtype=theta.dtype, device=theta.device)
+    if a < 1e-5:
+        return eye + 0.5 * K + (1.0 / 6.0) * K2
+    return eye + K * ((1.0 - torch.cos(a)) / (a ** 2)) + K2 * ((a - torch.sin(a)) / (a ** 3))
+
+
+def se3_exp(tau: torch.Tensor) -> torch.Tensor:
+    """tau = [rho; theta] -> 4x4."""
+    T = torch.eye(4, dtype=tau.dtype, device=tau.device)
+    T[:3, :3] = so3_exp(tau[3:])
+    T[:3, 3] = so3_left_jacobian(tau[3:]) @ tau[:3]
+    return T
+
+
+def retract_pose(R: torch.Tensor, t: torch.Tensor, rho: torch.Tensor, theta: torch.Tensor,
+                 converged_threshold: float = 1e-4):
+    """Left-multiplicative update used after every optimiser step.  Returns (R', t', converged)."""
+    tau = torch.cat([rho, theta])
+    T = torch.eye(4, dtype=tau.dtype, device=tau.device)
+    T[:3, :3] = R
+    T[:3, 3] = t
+    Tn = se3_exp(tau) @ T
+    return Tn[:3, :3], Tn[:3, 3], bool(tau.norm() < converged_threshold)
+
+
+class CameraMatrices(NamedTuple):
+    viewmatrix: torch.Tensor       # [4,4] transposed world->camera
+    projmatrix: torch.Tensor       # [4,4] transposed  P @ T_cw
+    projmatrix_raw: torch.Tensor   # [4,4] transposed  P
+    campos: torch.Tensor           # [3]
+    tanfovx: float
+    tanfovy: float
+
+
+def camera_matrices(R, t, fx, fy, cx, cy, W, H, device="cpu") -> CameraMatrices:
+    """Everything ``render()`` feeds into the settings tuple
+    (/root/reference/gaussian_splatting/gaussian_renderer/__init__.py:62-84)."""
+    view_t = world2view(R.to(device), t.to(device)).transpose(0, 1)
+    proj_t = projection_matrix(fx, fy, cx, cy, W, H, device=device).transpose(0, 1)
+    full_t = view_t.unsqueeze(0).bmm(proj_t.unsqueeze(0)).squeeze(0)
+    campos = view_t.inverse()[3, :3]
+    # float32 atan then a Python float, as /root/reference/utils/camera_utils.py:30-36 does
+    fovx = 2 * torch.atan(W / (2 * torch.tensor([float(fx)], dtype=torch.float32))).item()
+    fovy = 2 * torch.atan(H / (2 * torch.tensor([float(fy)], dtype=torch.float32))).item()
+    return CameraMatrices(view_t.contiguous(), full_t.contiguous(), proj_t.contiguous(), campos.contiguous(),
+                          math.tan(fovx * 0.5), math.tan(fovy * 0.5))
+
+
+# intrinsics of the reference's configs used by BASELINE.json
+INTRINSICS = {
+    # /root/reference/configs/mono/tum/fr3_office.yaml:6-16
+    "fr3_office": dict(fx=535.4, fy=539.2, cx=320.1, cy=247.6, W=640, H=480),
+    # /root/reference/configs/rgbd/replica/base_config.yaml:17-28
+    "replica": dict(fx=600.0, fy=600.0, cx=599.5, cy=339.5, W=1200, H=680),
+    # /root/reference/configs/mono/davis/car-turn.yaml:5-18 (the only 1920x1080 config)
+    "davis_1080p": dict(fx=960.0, fy=960.0, cx=960.0, cy=540.0, W=1920, H=1080),
+}

@@ -1,0 +1,26 @@
+"""CPU oracle for the MonoGS rasteriser hot path.  TEST INFRASTRUCTURE ONLY.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+this package, and only as the checker.  Nothing under ``monogs_amd/`` imports it; the product
+path fails loudly when the HIP library is missing instead of falling back to this code.
+
+PARITY UNPINNED: the reference's rasteriser and simple-knn are un-vendored submodules
+(/root/reference/.gitmodules:1-6, both directories empty), and the reference ships no tests,
+golden vectors or fixtures for this path.  The oracle is therefore a
+restatement of the published algorithm, pinned by
+  * the reference helpers that *do* import here (pose retraction, camera matrices, SH
+    evaluation; see tests/golden/make_golden.py and tests/test_golden.py),
+  * float64 ``torch.autograd.gradcheck`` and central finite differences of the pose Jacobian,
+  * known-answer cases (tests/test_oracle_kat.py).
+"""
+from .gs_oracle import (  # noqa: F401
+    OracleSettings,
+    preprocess,
+    build_binning,
+    rasterize,
+    rasterize_autograd,
+    se3_exp,
+    BLOCK_X,
+    BLOCK_Y,
+)
+from .knn_oracle import dist2_knn  # noqa: F401

@@ -1,0 +1,142 @@
+/* monogs_raster.h -- C ABI of libmonogs_raster.so (MI355X / gfx950 only).
+ *
+ * Drop-in boundary for the two native operators MonoGS calls:
+ *
+ *   diff_gaussian_rasterization   imported at /root/reference/gaussian_splatting/gaussian_renderer/__init__.py:13-16,
+ *                                 settings built at :70-84, called at :130-156
+ *   simple_knn._C.distCUDA2       imported at /root/reference/gaussian_splatting/scene/gaussian_model.py:18,
+ *                                 called at :294-302
+ *
+ * The reference binds these through pybind11 + torch::Tensor (there is no C plugin ABI upstream; the
+ * sources are un-vendored submodules, /root/reference/.gitmodules:1-6).  This header is the C-level
+ * contract of the same entry points: plain device pointers, sizes and a HIP stream; no torch types.
+ * The entry points correspond 1:1 to the upstream extension functions listed in SURVEY.md section 8b:
+ *
+ *   rasterize_gaussians            -> mgs_forward_preprocess + mgs_forward_render
+ *   rasterize_gaussians_backward   -> mgs_backward
+ *   mark_visible                   -> mgs_mark_visible
+ *   distCUDA2                      -> mgs_dist2_knn
+ *
+ * Conventions
+ *   - every pointer is DEVICE memory on the current HIP device unless marked [host];
+ *   - float tensors are contiguous float32; matrices are the 4x4 tensors MonoGS passes, i.e. the
+ *     TRANSPOSE of the maths matrix (flat element 4*j+i is maths element (i,j));
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream);
+ *   - every function returns 0 on success and a non-zero code on failure; mgs_last_error() gives the
+ *     message of the calling thread's last failure;
+ *   - the library keeps no state between calls: scratch lives in caller-owned buffers whose sizes come
+ *     from the mgs_*_bytes functions, so several forwards may precede one backward
+ *     (/root/reference/utils/slam_mapper.py:273-394) and several processes may share a GPU.
+ */
+#ifndef MONOGS_RASTER_H
+#define MONOGS_RASTER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MGS_ABI_VERSION 1
+#define MGS_TILE 16 /* tile edge in pixels; ranges are per 16x16 tile */
+
+/* GaussianRasterizationSettings, minus `prefiltered` / `debug` which are call flags
+ * (/root/reference/gaussian_splatting/gaussian_renderer/__init__.py:70-84). */
+typedef struct mgs_camera {
+    int32_t image_height;
+    int32_t image_width;
+    float tanfovx;
+    float tanfovy;
+    float scale_modifier;
+    int32_t sh_degree;           /* active SH degree (0..3); ignored with colors_precomp */
+    int32_t sh_coeffs;           /* M: coefficient triplets per Gaussian in `shs` (0 with colors_precomp) */
+    int32_t reserved;
+    const float* bg;             /* [3]  */
+    const float* viewmatrix;     /* [16] transposed world->camera */
+    const float* projmatrix;     /* [16] transposed P @ T_cw */
+    const float* projmatrix_raw; /* [16] transposed P */
+    const float* campos;         /* [3]  */
+} mgs_camera;
+
+/* Per-stage device time in milliseconds, measured with HIP events on `stream`.
+ * Passing a non-NULL mgs_timing makes the call synchronise `stream` before returning. */
+typedef struct mgs_timing {
+    float preprocess_ms;
+    float scan_ms;
+    float duplicate_ms;
+    float sort_ms;
+    float ranges_ms;
+    float blend_fwd_ms;
+    float blend_bwd_ms;
+    float geom_bwd_ms;
+} mgs_timing;
+
+int mgs_abi_version(void);
+const char* mgs_last_error(void);
+
+/* Scratch sizes (bytes).  geometry: per-Gaussian state carried from forward to backward;
+ * image: per-pixel and per-tile state; binning: keys / values / sort temp for R = num_rendered. */
+size_t mgs_geometry_bytes(int32_t P);
+size_t mgs_image_bytes(int32_t width, int32_t height);
+size_t mgs_binning_bytes(uint64_t num_rendered, int32_t width, int32_t height);
+size_t mgs_backward_bytes(int32_t P);
+
+/* Forward, stage 1: per-Gaussian projection (cull, covariance, radius, tile rectangle, colour) and the
+ * prefix sum of tiles touched.  Writes radii[P] and the geometry scratch, then copies the total number
+ * of (Gaussian, tile) instances to *num_rendered [host] -- this synchronises `stream`, exactly as the
+ * upstream forward does, because the caller must size the binning scratch from it.
+ * Exactly one of (shs, colors_precomp) and exactly one of ((scales, rotations), cov3D_precomp) is non-NULL. */
+int mgs_forward_preprocess(const mgs_camera* cam, int32_t P,
+                           const float* means3D,        /* [P,3] */
+                           const float* shs,            /* [P,M,3] or NULL */
+                           const float* colors_precomp, /* [P,3] or NULL */
+                           const float* opacities,      /* [P] */
+                           const float* scales,         /* [P,3] or NULL */
+                           const float* rotations,      /* [P,4] or NULL */
+                           const float* cov3D_precomp,  /* [P,6] or NULL */
+                           void* geometry, int32_t* radii /* [P] */,
+                           uint64_t* num_rendered /* [host] */,
+                           mgs_timing* timing /* [host] or NULL */, void* stream);
+
+/* Forward, stage 2: duplicate-with-keys, sort by (tile, depth), per-tile ranges, front-to-back blend.
+ * Outputs: color[3,H,W], depth[1,H,W] (sum z.alpha.T), opacity[1,H,W] (1 - T), n_touched[P]
+ * (zeroed here, then incremented per pixel where the Gaussian is blended with T.(1-alpha) > 0.5). */
+int mgs_forward_render(const mgs_camera* cam, int32_t P, uint64_t num_rendered,
+                       void* geometry, void* binning, void* image,
+                       float* out_color, float* out_depth, float* out_opacity, int32_t* n_touched,
+                       mgs_timing* timing, void* stream);
+
+/* Backward.  Consumes dL/dcolor[3,H,W] and dL/ddepth[1,H,W] (dL/dopacity is ignored, as upstream) and
+ * the scratch of the matching forward.  Any output pointer may be NULL (that gradient is then not
+ * stored); dL_dtau is [6] = (rho, theta), already summed over Gaussians. */
+int mgs_backward(const mgs_camera* cam, int32_t P, uint64_t num_rendered,
+                 const float* means3D, const float* shs, const float* colors_precomp,
+                 const float* opacities, const float* scales, const float* rotations,
+                 const float* cov3D_precomp, const int32_t* radii,
+                 const void* geometry, const void* binning, const void* image,
+                 const float* dL_dcolor, const float* dL_ddepth,
+                 float* dL_dmeans2D,  /* [P,3] NDC-scaled x,y; z = 0 */
+                 float* dL_dcolors,   /* [P,3] (colors_precomp) */
+                 float* dL_dopacity,  /* [P]   */
+                 float* dL_dmeans3D,  /* [P,3] */
+                 float* dL_dcov3D,    /* [P,6] (cov3D_precomp) */
+                 float* dL_dsh,       /* [P,M,3] (shs) */
+                 float* dL_dscales,   /* [P,3] */
+                 float* dL_drotations,/* [P,4] */
+                 float* dL_dtau,      /* [6]   */
+                 void* backward_scratch, mgs_timing* timing, void* stream);
+
+/* visible[P] (1 byte each) = view-space z > 0.2 (upstream markVisible; unused by MonoGS). */
+int mgs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                     uint8_t* visible, void* stream);
+
+/* out[P] = mean squared distance to the 3 nearest other points (exact). */
+size_t mgs_knn_scratch_bytes(int32_t P);
+int mgs_dist2_knn(int32_t P, const float* points /* [P,3] */, float* out /* [P] */,
+                  void* scratch, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MONOGS_RASTER_H */

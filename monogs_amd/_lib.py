@@ -1,0 +1,89 @@
+"""ctypes binding of libmonogs_raster.so (the C ABI declared in include/monogs_raster.h).
+
+There is no fallback: if the library is missing, stale or fails to load, importing the product
+path raises.  The library is built in-tree (monogs_amd/lib/) by ``__graft_entry__.build()`` or
+``make -C monogs_amd/csrc``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmonogs_raster.so")
+ABI_VERSION = 1
+
+c_float_p = C.c_void_p   # device pointers travel as integers (tensor.data_ptr())
+
+
+class MgsCamera(C.Structure):
+    _fields_ = [
+        ("image_height", C.c_int32), ("image_width", C.c_int32),
+        ("tanfovx", C.c_float), ("tanfovy", C.c_float), ("scale_modifier", C.c_float),
+        ("sh_degree", C.c_int32), ("sh_coeffs", C.c_int32), ("reserved", C.c_int32),
+        ("bg", C.c_void_p), ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p),
+        ("projmatrix_raw", C.c_void_p), ("campos", C.c_void_p),
+    ]
+
+
+class MgsTiming(C.Structure):
+    _fields_ = [(n, C.c_float) for n in (
+        "preprocess_ms", "scan_ms", "duplicate_ms", "sort_ms", "ranges_ms", "blend_fwd_ms",
+        "blend_bwd_ms", "geom_bwd_ms")]
+
+    def as_dict(self):
+        return {n: float(getattr(self, n)) for n, _ in self._fields_}
+
+
+# symbol -> (restype, argtypes); exactly the declarations of include/monogs_raster.h
+SIGNATURES = {
+    "mgs_abi_version": (C.c_int, []),
+    "mgs_last_error": (C.c_char_p, []),
+    "mgs_geometry_bytes": (C.c_size_t, [C.c_int32]),
+    "mgs_image_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
+    "mgs_binning_bytes": (C.c_size_t, [C.c_uint64, C.c_int32, C.c_int32]),
+    "mgs_backward_bytes": (C.c_size_t, [C.c_int32]),
+    "mgs_forward_preprocess": (C.c_int, [C.POINTER(MgsCamera), C.c_int32] + [C.c_void_p] * 7
+                               + [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(MgsTiming), C.c_void_p]),
+    "mgs_forward_render": (C.c_int, [C.POINTER(MgsCamera), C.c_int32, C.c_uint64] + [C.c_void_p] * 7
+                           + [C.POINTER(MgsTiming), C.c_void_p]),
+    "mgs_backward": (C.c_int, [C.POINTER(MgsCamera), C.c_int32, C.c_uint64] + [C.c_void_p] * 7
+                     + [C.c_void_p] * 4 + [C.c_void_p] * 2 + [C.c_void_p] * 9
+                     + [C.c_void_p, C.POINTER(MgsTiming), C.c_void_p]),
+    "mgs_mark_visible": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mgs_knn_scratch_bytes": (C.c_size_t, [C.c_int32]),
+    "mgs_dist2_knn": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+}
+
+_lib = None
+
+
+class MonoGSNativeError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and return the ctypes handle.  Raises if the HIP library is unavailable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MonoGSNativeError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C monogs_amd/csrc`.  There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the .so is stale
+        fn.restype = res
+        fn.argtypes = args
+    if lib.mgs_abi_version() != ABI_VERSION:
+        raise MonoGSNativeError(f"ABI mismatch: library {lib.mgs_abi_version()} vs binding {ABI_VERSION}; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().mgs_last_error().decode("utf-8", "replace")
+        # argument errors mirror the upstream extension's Python exceptions
+        raise Exception(msg) if rc == 1 else MonoGSNativeError(f"{what}: {msg}")

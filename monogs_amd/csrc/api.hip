@@ -1,0 +1,266 @@
+// extern "C" entry points of libmonogs_raster.so (see include/monogs_raster.h).
+#include "common.h"
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+namespace mgs {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// ---- scratch carving -------------------------------------------------------------------------
+static inline char* take(char*& p, size_t bytes) {
+    char* r = p;
+    p += align_up(bytes, 256);
+    return r;
+}
+
+size_t GeometryState::bytes(int P) {
+    char* p = nullptr;
+    take(p, (size_t)P * REC_FLOATS * sizeof(float));
+    take(p, (size_t)P * sizeof(uint32_t));
+    take(p, (size_t)P * sizeof(uint32_t));
+    take(p, ((size_t)scan_nblocks(P) + 64) * sizeof(uint32_t));
+    take(p, (size_t)P * 4);
+    return (size_t)(p - (char*)nullptr) + 256;
+}
+GeometryState GeometryState::carve(void* base, int P) {
+    char* p = (char*)align_up((size_t)base, 256);
+    GeometryState g;
+    g.rec = (float*)take(p, (size_t)P * REC_FLOATS * sizeof(float));
+    g.tiles_touched = (uint32_t*)take(p, (size_t)P * sizeof(uint32_t));
+    g.point_offsets = (uint32_t*)take(p, (size_t)P * sizeof(uint32_t));
+    g.scan_blocks = (uint32_t*)take(p, ((size_t)scan_nblocks(P) + 64) * sizeof(uint32_t));
+    g.clamped = (uint8_t*)take(p, (size_t)P * 4);
+    return g;
+}
+
+size_t ImageState::bytes(int W, int H) {
+    const size_t HW = (size_t)W * H, nt = (size_t)tiles_x(W) * tiles_y(H);
+    return align_up(HW * 4, 256) * 2 + align_up(nt * sizeof(uint2), 256) + 256;
+}
+ImageState ImageState::carve(void* base, int W, int H) {
+    const size_t HW = (size_t)W * H, nt = (size_t)tiles_x(W) * tiles_y(H);
+    char* p = (char*)align_up((size_t)base, 256);
+    ImageState s;
+    s.final_T = (float*)take(p, HW * 4);
+    s.n_contrib = (uint32_t*)take(p, HW * 4);
+    s.ranges = (uint2*)take(p, nt * sizeof(uint2));
+    return s;
+}
+
+size_t BinningState::bytes(uint64_t R, int W, int H) {
+    const size_t r = (size_t)(R ? R : 1);
+    return align_up(r * 8, 256) * 2 + align_up(r * 4, 256) * 2 + align_up(mgs::sort_temp_bytes(R, key_bits(W, H)), 256) + 256;
+}
+BinningState BinningState::carve(void* base, uint64_t R, int W, int H) {
+    const size_t r = (size_t)(R ? R : 1);
+    char* p = (char*)align_up((size_t)base, 256);
+    BinningState b;
+    b.keys_unsorted = (uint64_t*)take(p, r * 8);
+    b.keys_sorted = (uint64_t*)take(p, r * 8);
+    b.vals_unsorted = (uint32_t*)take(p, r * 4);
+    b.vals_sorted = (uint32_t*)take(p, r * 4);
+    b.sort_temp_bytes = mgs::sort_temp_bytes(R, key_bits(W, H));
+    b.sort_temp = take(p, b.sort_temp_bytes);
+    return b;
+}
+
+// ---- per-stage timing with HIP events on the launch stream -------------------------------
+struct StageTimer {
+    hipStream_t s;
+    bool on;
+    hipEvent_t ev[10];
+    int n = 0;
+    StageTimer(hipStream_t s_, bool on_) : s(s_), on(on_) {
+        if (on) for (auto& e : ev) (void)hipEventCreate(&e);
+    }
+    ~StageTimer() {
+        if (on) for (auto& e : ev) (void)hipEventDestroy(e);
+    }
+    void mark() {
+        if (on && n < 10) (void)hipEventRecord(ev[n++], s);
+    }
+    float ms(int i) {   // time between mark i and mark i+1
+        float t = 0.f;
+        if (on && i + 1 < n) (void)hipEventElapsedTime(&t, ev[i], ev[i + 1]);
+        return t;
+    }
+    void sync() {
+        if (on && n) (void)hipEventSynchronize(ev[n - 1]);
+    }
+};
+
+static int check_cam(const mgs_camera* cam) {
+    if (!cam) { set_error("camera is NULL"); return 1; }
+    if (cam->image_width <= 0 || cam->image_height <= 0) { set_error("image size must be positive"); return 1; }
+    if (!cam->bg || !cam->viewmatrix || !cam->projmatrix || !cam->projmatrix_raw || !cam->campos) {
+        set_error("camera tensors (bg, viewmatrix, projmatrix, projmatrix_raw, campos) must be non-NULL");
+        return 1;
+    }
+    return 0;
+}
+
+}  // namespace mgs
+
+using namespace mgs;
+
+extern "C" {
+
+int mgs_abi_version(void) { return MGS_ABI_VERSION; }
+const char* mgs_last_error(void) { return g_err; }
+
+size_t mgs_geometry_bytes(int32_t P) { return GeometryState::bytes(P < 0 ? 0 : P); }
+size_t mgs_image_bytes(int32_t W, int32_t H) { return ImageState::bytes(W, H); }
+size_t mgs_binning_bytes(uint64_t R, int32_t W, int32_t H) { return BinningState::bytes(R, W, H); }
+size_t mgs_backward_bytes(int32_t P) { return (size_t)(P < 0 ? 0 : P) * GRAD_FLOATS * sizeof(float) + 256; }
+
+int mgs_forward_preprocess(const mgs_camera* cam, int32_t P, const float* means3D, const float* shs,
+                           const float* colors_precomp, const float* opacities, const float* scales,
+                           const float* rotations, const float* cov3D_precomp, void* geometry, int32_t* radii,
+                           uint64_t* num_rendered, mgs_timing* timing, void* stream) {
+    if (check_cam(cam)) return 1;
+    if (P < 0) { set_error("P must be >= 0"); return 1; }
+    if (!num_rendered) { set_error("num_rendered is NULL"); return 1; }
+    *num_rendered = 0;
+    if (P == 0) return 0;
+    if (!means3D || !opacities || !geometry || !radii) { set_error("means3D, opacities, geometry, radii must be non-NULL"); return 1; }
+    if ((shs == nullptr) == (colors_precomp == nullptr)) {
+        set_error("Please provide excatly one of either SHs or precomputed colors!");
+        return 1;
+    }
+    const bool have_sr = scales != nullptr || rotations != nullptr;
+    if ((have_sr && (!scales || !rotations || cov3D_precomp)) || (!have_sr && !cov3D_precomp)) {
+        set_error("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!");
+        return 1;
+    }
+    if (shs && (cam->sh_degree < 0 || cam->sh_degree > 3 || cam->sh_coeffs < (cam->sh_degree + 1) * (cam->sh_degree + 1))) {
+        set_error("sh_degree must be 0..3 and shs must hold at least (degree+1)^2 coefficients");
+        return 1;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    GeometryState g = GeometryState::carve(geometry, P);
+    StageTimer tm(s, timing != nullptr);
+    tm.mark();
+    if (int rc = launch_preprocess_forward(*cam, P, means3D, shs, colors_precomp, opacities, scales, rotations,
+                                           cov3D_precomp, g, radii, s)) return rc;
+    tm.mark();
+    if (int rc = launch_scan(g, P, s)) return rc;
+    tm.mark();
+    uint32_t total = 0;
+    MGS_HIP(hipMemcpyAsync(&total, g.point_offsets + (P - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    MGS_HIP(hipStreamSynchronize(s));
+    *num_rendered = total;
+    if (timing) {
+        timing->preprocess_ms = tm.ms(0);
+        timing->scan_ms = tm.ms(1);
+    }
+    return 0;
+}
+
+int mgs_forward_render(const mgs_camera* cam, int32_t P, uint64_t R, void* geometry, void* binning, void* image,
+                       float* out_color, float* out_depth, float* out_opacity, int32_t* n_touched,
+                       mgs_timing* timing, void* stream) {
+    if (check_cam(cam)) return 1;
+    if (!image || !out_color || !out_depth || !out_opacity) { set_error("image scratch and outputs must be non-NULL"); return 1; }
+    if (P > 0 && (!geometry || !n_touched)) { set_error("geometry and n_touched must be non-NULL"); return 1; }
+    if (R > 0 && !binning) { set_error("binning scratch is NULL"); return 1; }
+    if (R >= (1ull << 32)) { set_error("num_rendered exceeds 2^32-1"); return 1; }
+    hipStream_t s = (hipStream_t)stream;
+    const int W = cam->image_width, H = cam->image_height;
+    GeometryState g = GeometryState::carve(geometry, P);
+    ImageState img = ImageState::carve(image, W, H);
+    BinningState b = BinningState::carve(binning, R, W, H);
+    StageTimer tm(s, timing != nullptr);
+    if (P > 0) MGS_HIP(hipMemsetAsync(n_touched, 0, (size_t)P * sizeof(int32_t), s));
+    tm.mark();
+    if (R > 0) {
+        if (int rc = launch_duplicate(*cam, P, g, b, s)) return rc;
+    }
+    tm.mark();
+    if (int rc = launch_sort(b, R, key_bits(W, H), s)) return rc;
+    tm.mark();
+    if (int rc = launch_ranges(b, R, img, tiles_x(W) * tiles_y(H), s)) return rc;
+    tm.mark();
+    if (int rc = launch_blend_forward(*cam, g, b, img, out_color, out_depth, out_opacity, n_touched, s)) return rc;
+    tm.mark();
+    if (timing) {
+        tm.sync();
+        timing->duplicate_ms = tm.ms(0);
+        timing->sort_ms = tm.ms(1);
+        timing->ranges_ms = tm.ms(2);
+        timing->blend_fwd_ms = tm.ms(3);
+    }
+    return 0;
+}
+
+int mgs_backward(const mgs_camera* cam, int32_t P, uint64_t R, const float* means3D, const float* shs,
+                 const float* colors_precomp, const float* opacities, const float* scales, const float* rotations,
+                 const float* cov3D_precomp, const int32_t* radii, const void* geometry, const void* binning,
+                 const void* image, const float* dL_dcolor, const float* dL_ddepth, float* dL_dmeans2D,
+                 float* dL_dcolors, float* dL_dopacity, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh,
+                 float* dL_dscales, float* dL_drotations, float* dL_dtau, void* backward_scratch,
+                 mgs_timing* timing, void* stream) {
+    if (check_cam(cam)) return 1;
+    hipStream_t s = (hipStream_t)stream;
+    if (P == 0) {
+        if (dL_dtau) MGS_HIP(hipMemsetAsync(dL_dtau, 0, 6 * sizeof(float), s));
+        return 0;
+    }
+    if (!means3D || !opacities || !radii || !geometry || !image || !dL_dcolor || !dL_ddepth || !backward_scratch) {
+        set_error("means3D, opacities, radii, geometry, image, dL_dcolor, dL_ddepth, backward_scratch must be non-NULL");
+        return 1;
+    }
+    if (R > 0 && !binning) { set_error("binning scratch is NULL"); return 1; }
+    const int W = cam->image_width, H = cam->image_height;
+    GeometryState g = GeometryState::carve(const_cast<void*>(geometry), P);
+    ImageState img = ImageState::carve(const_cast<void*>(image), W, H);
+    BinningState b = BinningState::carve(const_cast<void*>(binning), R, W, H);
+    float* grad_acc = (float*)align_up((size_t)backward_scratch, 256);
+    StageTimer tm(s, timing != nullptr);
+    MGS_HIP(hipMemsetAsync(grad_acc, 0, (size_t)P * GRAD_FLOATS * sizeof(float), s));
+    tm.mark();
+    if (R > 0) {
+        if (int rc = launch_blend_backward(*cam, g, b, img, dL_dcolor, dL_ddepth, grad_acc, s)) return rc;
+    }
+    tm.mark();
+    GeomBackwardArgs a;
+    a.means3D = means3D; a.shs = shs; a.colors_precomp = colors_precomp; a.opacities = opacities;
+    a.scales = scales; a.rotations = rotations; a.cov3D_precomp = cov3D_precomp; a.radii = radii;
+    a.grad_acc = grad_acc;
+    a.dL_dmeans2D = dL_dmeans2D; a.dL_dcolors = dL_dcolors; a.dL_dopacity = dL_dopacity;
+    a.dL_dmeans3D = dL_dmeans3D; a.dL_dcov3D = dL_dcov3D; a.dL_dsh = dL_dsh; a.dL_dscales = dL_dscales;
+    a.dL_drotations = dL_drotations; a.dL_dtau = dL_dtau;
+    if (int rc = launch_geom_backward(*cam, P, g, a, s)) return rc;
+    tm.mark();
+    if (timing) {
+        tm.sync();
+        timing->blend_bwd_ms = tm.ms(0);
+        timing->geom_bwd_ms = tm.ms(1);
+    }
+    return 0;
+}
+
+int mgs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                     uint8_t* visible, void* stream) {
+    (void)projmatrix;
+    if (P < 0 || (P > 0 && (!means3D || !viewmatrix || !visible))) { set_error("bad arguments"); return 1; }
+    return launch_mark_visible(P, means3D, viewmatrix, visible, (hipStream_t)stream);
+}
+
+size_t mgs_knn_scratch_bytes(int32_t P) { return knn_scratch_bytes(P); }
+
+int mgs_dist2_knn(int32_t P, const float* points, float* out, void* scratch, void* stream) {
+    if (P < 0 || (P > 0 && (!points || !out))) { set_error("bad arguments"); return 1; }
+    return launch_knn(P, points, out, scratch, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,117 @@
+// Internal definitions shared by the HIP translation units of libmonogs_raster.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "../../include/monogs_raster.h"
+
+namespace mgs {
+
+constexpr int TILE = MGS_TILE;          // 16x16 pixel tiles define the binning tables
+constexpr int WAVE = 64;                // gfx950 wavefront
+constexpr int SUB = 8;                  // one wave blends an 8x8 quadrant of a tile
+constexpr int REC_FLOATS = 16;          // per-Gaussian blend record: one 64-byte line
+constexpr int GRAD_FLOATS = 16;         // per-Gaussian gradient accumulator: one 64-byte line
+
+// blend record slots (float index inside the 64-byte record written by preprocess)
+enum : int {
+    R_X = 0, R_Y = 1, R_DEPTH = 2, R_OPAC = 3,
+    R_CA = 4, R_CB = 5, R_CC = 6, R_EX = 7,
+    R_R = 8, R_G = 9, R_B = 10, R_EY = 11,
+    R_COVXX = 12, R_COVXY = 13, R_COVYY = 14, R_SPARE = 15
+};
+// gradient accumulator slots (written with float atomics by the blend backward)
+enum : int {
+    G_DX = 0, G_DY = 1, G_DCA = 2, G_DCB = 3, G_DCC = 4, G_DOP = 5,
+    G_DR = 6, G_DG = 7, G_DB = 8, G_DDEPTH = 9
+};
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ---- scratch carving (every sub-buffer 256-byte aligned) ---------------------------------
+struct GeometryState {
+    float* rec;               // [P][16]
+    uint32_t* tiles_touched;  // [P]
+    uint32_t* point_offsets;  // [P] inclusive scan of tiles_touched
+    uint32_t* scan_blocks;    // [scan_nblocks(P) + 64]
+    uint8_t* clamped;         // [P][4] SH colour clamp flags
+    static size_t bytes(int P);
+    static GeometryState carve(void* base, int P);
+};
+
+struct ImageState {
+    float* final_T;      // [H*W]
+    uint32_t* n_contrib; // [H*W]
+    uint2* ranges;       // [tiles]
+    static size_t bytes(int W, int H);
+    static ImageState carve(void* base, int W, int H);
+};
+
+struct BinningState {
+    uint64_t* keys_unsorted;
+    uint64_t* keys_sorted;
+    uint32_t* vals_unsorted;
+    uint32_t* vals_sorted;     // "point_list": Gaussian index per instance, blend order
+    void* sort_temp;
+    size_t sort_temp_bytes;
+    static size_t bytes(uint64_t R, int W, int H);
+    static BinningState carve(void* base, uint64_t R, int W, int H);
+};
+
+constexpr int SCAN_ITEMS = 2048;   // items per scan block
+inline int scan_nblocks(int P) { return (P + SCAN_ITEMS - 1) / SCAN_ITEMS; }
+
+inline int tiles_x(int W) { return (W + TILE - 1) / TILE; }
+inline int tiles_y(int H) { return (H + TILE - 1) / TILE; }
+inline int key_bits(int W, int H) {      // bits of (tile_id << 32 | depth) that can be set
+    uint32_t n = (uint32_t)(tiles_x(W) * tiles_y(H));
+    int b = 0;
+    while ((1u << b) < n && b < 31) ++b;
+    return 32 + (b == 0 ? 1 : b);
+}
+
+// ---- error plumbing --------------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+#define MGS_HIP(expr)                                                                     \
+    do {                                                                                  \
+        hipError_t _e = (expr);                                                           \
+        if (_e != hipSuccess) {                                                           \
+            mgs::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return 2;                                                                     \
+        }                                                                                 \
+    } while (0)
+
+// ---- stage launchers (one per translation unit) ------------------------------------------
+struct StageTimer;  // api.hip
+
+int launch_preprocess_forward(const mgs_camera& cam, int P, const float* means3D, const float* shs,
+                              const float* colors_precomp, const float* opacities, const float* scales,
+                              const float* rotations, const float* cov3D_precomp,
+                              const GeometryState& g, int32_t* radii, hipStream_t s);
+int launch_scan(const GeometryState& g, int P, hipStream_t s);
+int launch_duplicate(const mgs_camera& cam, int P, const GeometryState& g, const BinningState& b, hipStream_t s);
+size_t sort_temp_bytes(uint64_t R, int bits);
+int launch_sort(const BinningState& b, uint64_t R, int bits, hipStream_t s);
+int launch_ranges(const BinningState& b, uint64_t R, const ImageState& img, int ntiles, hipStream_t s);
+int launch_blend_forward(const mgs_camera& cam, const GeometryState& g, const BinningState& b,
+                         const ImageState& img, float* out_color, float* out_depth, float* out_opacity,
+                         int32_t* n_touched, hipStream_t s);
+int launch_blend_backward(const mgs_camera& cam, const GeometryState& g, const BinningState& b,
+                          const ImageState& img, const float* dL_dcolor, const float* dL_ddepth,
+                          float* grad_acc, hipStream_t s);
+struct GeomBackwardArgs {
+    const float *means3D, *shs, *colors_precomp, *opacities, *scales, *rotations, *cov3D_precomp;
+    const int32_t* radii;
+    const float* grad_acc;   // [P][16] from the blend backward
+    float *dL_dmeans2D, *dL_dcolors, *dL_dopacity, *dL_dmeans3D, *dL_dcov3D, *dL_dsh, *dL_dscales,
+        *dL_drotations, *dL_dtau;
+};
+int launch_geom_backward(const mgs_camera& cam, int P, const GeometryState& g, const GeomBackwardArgs& a,
+                         hipStream_t s);
+int launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* visible, hipStream_t s);
+size_t knn_scratch_bytes(int P);
+int launch_knn(int P, const float* points, float* out, void* scratch, hipStream_t s);
+
+}  // namespace mgs

@@ -1,0 +1,572 @@
+// Per-Gaussian kernels: forward projection (cull, EWA covariance, radius, tile rectangle, colour)
+// and the matching backward (dL/d{mean3D, scale, rotation, cov3D, SH, tau}).
+//
+// Boundary replaced: upstream `preprocessCUDA` forward/backward + `computeCov2DCUDA` backward of the
+// un-vendored rasteriser; maths corroborated by
+// /root/reference/viewer/gl_render/shaders/gau_vert.glsl:60-107,149-154,173-210 and
+// /root/reference/gaussian_splatting/utils/general_utils.py:113-136; pose convention from
+// /root/reference/utils/pose_utils.py:61-93.
+//
+// The geometry that decides integers (radius, tile rectangle) and sort keys (depth bits) is computed
+// with one IEEE operation per source operator in a fixed association order, and this file is built
+// with FP contraction off, so a float32 CPU restatement reproduces those integers bit for bit.
+#include "common.h"
+
+#pragma clang fp contract(off)
+
+namespace mgs {
+
+__device__ __forceinline__ float dot3p(float m0, float m1, float m2, float m3, float x, float y, float z) {
+    return ((m0 * x + m1 * y) + m2 * z) + m3;
+}
+
+// SH basis constants (/root/reference/gaussian_splatting/utils/sh_utils.py:24-52)
+__device__ constexpr float SH_C0 = 0.28209479177387814f;
+__device__ constexpr float SH_C1 = 0.4886025119029199f;
+__device__ constexpr float SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                       -1.0925484305920792f, 0.5462742152960396f};
+__device__ constexpr float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                                       0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f,
+                                       -0.5900435899266435f};
+
+struct Cam {
+    float V[16], PM[16], PR[16];
+    float campos[3];
+    float tanfovx, tanfovy, focal_x, focal_y, mod;
+    int W, H, gx, gy, deg, M;
+};
+
+__device__ __forceinline__ void load_cam(Cam& c, const float* V, const float* PM, const float* PR,
+                                         const float* campos) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { c.V[i] = V[i]; c.PM[i] = PM[i]; c.PR[i] = PR ? PR[i] : 0.f; }
+    c.campos[0] = campos[0]; c.campos[1] = campos[1]; c.campos[2] = campos[2];
+}
+
+__device__ __forceinline__ void cov3d_from_scale_rot(const float s[3], const float q[4], float mod, float cov[6],
+                                                     float Mm[9]) {
+    const float r = q[0], x = q[1], y = q[2], z = q[3];
+    float Rm[9] = {1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y),
+                   2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x),
+                   2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y)};
+    const float sx = s[0] * mod, sy = s[1] * mod, sz = s[2] * mod;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        Mm[3 * i + 0] = Rm[3 * i + 0] * sx;
+        Mm[3 * i + 1] = Rm[3 * i + 1] * sy;
+        Mm[3 * i + 2] = Rm[3 * i + 2] * sz;
+    }
+    auto e = [&](int i, int j) {
+        return (Mm[3 * i] * Mm[3 * j] + Mm[3 * i + 1] * Mm[3 * j + 1]) + Mm[3 * i + 2] * Mm[3 * j + 2];
+    };
+    cov[0] = e(0, 0); cov[1] = e(0, 1); cov[2] = e(0, 2);
+    cov[3] = e(1, 1); cov[4] = e(1, 2); cov[5] = e(2, 2);
+}
+
+// EWA projection intermediates shared by forward and backward
+struct Proj {
+    float tx, ty, tz;        // clamped view-space mean used by the Jacobian
+    bool clamp_x, clamp_y;
+    float J00, J02, J11, J12;
+    float T0[3], T1[3];
+    float cxx, cxy, cyy;     // 2-D covariance incl. the +0.3 low-pass
+};
+
+__device__ __forceinline__ void project_cov(const Cam& c, const float pv[3], const float cov[6], Proj& p) {
+    const float limx = 1.3f * c.tanfovx, limy = 1.3f * c.tanfovy;
+    const float tz = pv[2];
+    const float txtz = pv[0] / tz, tytz = pv[1] / tz;
+    p.clamp_x = (txtz < -limx) || (txtz > limx);
+    p.clamp_y = (tytz < -limy) || (tytz > limy);
+    p.tx = fminf(limx, fmaxf(-limx, txtz)) * tz;
+    p.ty = fminf(limy, fmaxf(-limy, tytz)) * tz;
+    p.tz = tz;
+    const float tz2 = tz * tz;
+    p.J00 = c.focal_x / tz;
+    p.J02 = -(c.focal_x * p.tx) / tz2;
+    p.J11 = c.focal_y / tz;
+    p.J12 = -(c.focal_y * p.ty) / tz2;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {       // Rv(i,j) = V[4*j+i]
+        p.T0[j] = p.J00 * c.V[4 * j + 0] + p.J02 * c.V[4 * j + 2];
+        p.T1[j] = p.J11 * c.V[4 * j + 1] + p.J12 * c.V[4 * j + 2];
+    }
+    const float S[3][3] = {{cov[0], cov[1], cov[2]}, {cov[1], cov[3], cov[4]}, {cov[2], cov[4], cov[5]}};
+    float U0[3], U1[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        U0[j] = (p.T0[0] * S[0][j] + p.T0[1] * S[1][j]) + p.T0[2] * S[2][j];
+        U1[j] = (p.T1[0] * S[0][j] + p.T1[1] * S[1][j]) + p.T1[2] * S[2][j];
+    }
+    p.cxx = ((U0[0] * p.T0[0] + U0[1] * p.T0[1]) + U0[2] * p.T0[2]) + 0.3f;
+    p.cxy = (U0[0] * p.T1[0] + U0[1] * p.T1[1]) + U0[2] * p.T1[2];
+    p.cyy = ((U1[0] * p.T1[0] + U1[1] * p.T1[1]) + U1[2] * p.T1[2]) + 0.3f;
+}
+
+__device__ __forceinline__ void tile_rect(float px, float py, float radius, int gx, int gy, int& x0, int& y0,
+                                          int& x1, int& y1) {
+    x0 = min(gx, max(0, (int)((px - radius) / (float)TILE)));
+    y0 = min(gy, max(0, (int)((py - radius) / (float)TILE)));
+    x1 = min(gx, max(0, (int)(((px + radius) + (float)(TILE - 1)) / (float)TILE)));
+    y1 = min(gy, max(0, (int)(((py + radius) + (float)(TILE - 1)) / (float)TILE)));
+}
+
+// Direction-dependent colour.  sh: [M][3] for this Gaussian.
+__device__ __forceinline__ void eval_sh(int deg, const float* sh, const float d[3], float out[3]) {
+    const float x = d[0], y = d[1], z = d[2];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        float res = SH_C0 * sh[ch];
+        if (deg > 0) {
+            res = res - SH_C1 * y * sh[3 + ch] + SH_C1 * z * sh[6 + ch] - SH_C1 * x * sh[9 + ch];
+            if (deg > 1) {
+                const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                res = res + SH_C2[0] * xy * sh[12 + ch] + SH_C2[1] * yz * sh[15 + ch] +
+                      SH_C2[2] * (2.f * zz - xx - yy) * sh[18 + ch] + SH_C2[3] * xz * sh[21 + ch] +
+                      SH_C2[4] * (xx - yy) * sh[24 + ch];
+                if (deg > 2) {
+                    res = res + SH_C3[0] * y * (3.f * xx - yy) * sh[27 + ch] + SH_C3[1] * xy * z * sh[30 + ch] +
+                          SH_C3[2] * y * (4.f * zz - xx - yy) * sh[33 + ch] +
+                          SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy) * sh[36 + ch] +
+                          SH_C3[4] * x * (4.f * zz - xx - yy) * sh[39 + ch] + SH_C3[5] * z * (xx - yy) * sh[42 + ch] +
+                          SH_C3[6] * x * (xx - 3.f * yy) * sh[45 + ch];
+                }
+            }
+        }
+        out[ch] = res + 0.5f;
+    }
+}
+
+struct PreArgs {
+    const float *means3D, *shs, *colors, *opacities, *scales, *rotations, *cov3D;
+    const float *V, *PM, *campos;
+    float* rec;
+    uint32_t* tiles_touched;
+    uint8_t* clamped;
+    int32_t* radii;
+    float tanfovx, tanfovy, focal_x, focal_y, mod;
+    int P, W, H, gx, gy, deg, M;
+};
+
+__global__ void __launch_bounds__(256) preprocess_forward_kernel(PreArgs a) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= a.P) return;
+    a.radii[idx] = 0;
+    a.tiles_touched[idx] = 0;
+
+    Cam c;
+    load_cam(c, a.V, a.PM, nullptr, a.campos);
+    c.tanfovx = a.tanfovx; c.tanfovy = a.tanfovy; c.focal_x = a.focal_x; c.focal_y = a.focal_y;
+
+    const float x = a.means3D[3 * idx], y = a.means3D[3 * idx + 1], z = a.means3D[3 * idx + 2];
+    float pv[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) pv[k] = dot3p(c.V[k], c.V[4 + k], c.V[8 + k], c.V[12 + k], x, y, z);
+    if (!(pv[2] > 0.2f)) return;                          // near cull (also rejects NaN)
+    float ph[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ph[k] = dot3p(c.PM[k], c.PM[4 + k], c.PM[8 + k], c.PM[12 + k], x, y, z);
+    const float p_w = 1.0f / (ph[3] + 0.0000001f);
+    const float projx = ph[0] * p_w, projy = ph[1] * p_w;
+
+    float cov[6];
+    if (a.cov3D) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) cov[k] = a.cov3D[6 * idx + k];
+    } else {
+        const float s[3] = {a.scales[3 * idx], a.scales[3 * idx + 1], a.scales[3 * idx + 2]};
+        const float q[4] = {a.rotations[4 * idx], a.rotations[4 * idx + 1], a.rotations[4 * idx + 2],
+                            a.rotations[4 * idx + 3]};
+        float Mm[9];
+        cov3d_from_scale_rot(s, q, a.mod, cov, Mm);
+    }
+    Proj p;
+    project_cov(c, pv, cov, p);
+    const float det = p.cxx * p.cyy - p.cxy * p.cxy;
+    if (det == 0.0f) return;
+    const float det_inv = 1.f / det;
+    const float ca = p.cyy * det_inv, cb = -p.cxy * det_inv, cc = p.cxx * det_inv;
+    const float mid = 0.5f * (p.cxx + p.cyy);
+    const float disc = sqrtf(fmaxf(0.1f, mid * mid - det));
+    const float lam = fmaxf(mid + disc, mid - disc);
+    const float radius = ceilf(3.f * sqrtf(lam));
+    const float px = ((projx + 1.0f) * (float)a.W - 1.0f) * 0.5f;
+    const float py = ((projy + 1.0f) * (float)a.H - 1.0f) * 0.5f;
+    if (!(isfinite(px) && isfinite(py) && isfinite(radius))) return;
+    int x0, y0, x1, y1;
+    tile_rect(px, py, radius, a.gx, a.gy, x0, y0, x1, y1);
+    const int ntile = (x1 - x0) * (y1 - y0);
+    if (ntile == 0) return;
+
+    float rgb[3];
+    if (a.colors) {
+        rgb[0] = a.colors[3 * idx]; rgb[1] = a.colors[3 * idx + 1]; rgb[2] = a.colors[3 * idx + 2];
+    } else {
+        float d[3] = {x - c.campos[0], y - c.campos[1], z - c.campos[2]};
+        const float len = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
+        d[0] = d[0] / len; d[1] = d[1] / len; d[2] = d[2] / len;
+        eval_sh(a.deg, a.shs + (size_t)idx * a.M * 3, d, rgb);
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            a.clamped[4 * idx + ch] = rgb[ch] < 0.f;
+            rgb[ch] = fmaxf(rgb[ch], 0.f);
+        }
+    }
+
+    const float opac = a.opacities[idx];
+    // Half extents of the axis-aligned box around the alpha >= 1/255 ellipse, padded: the blend
+    // kernels skip an instance for a whole 8x8 quadrant when the box misses the quadrant, which
+    // cannot change any pixel because every skipped pair has alpha < 1/255.
+    float ex = -1.f, ey = -1.f;
+    const float tau = logf(255.0f * opac);
+    if (tau > 0.f) {
+        ex = sqrtf(2.f * tau * p.cxx) * 1.001f + 0.05f;
+        ey = sqrtf(2.f * tau * p.cyy) * 1.001f + 0.05f;
+    } else if (!(tau <= 0.f)) {   // NaN opacity: never skip, let the blend propagate it
+        ex = ey = 3.0e38f;
+    }
+
+    float4* rec = reinterpret_cast<float4*>(a.rec + (size_t)idx * REC_FLOATS);
+    rec[0] = make_float4(px, py, pv[2], opac);
+    rec[1] = make_float4(ca, cb, cc, ex);
+    rec[2] = make_float4(rgb[0], rgb[1], rgb[2], ey);
+    rec[3] = make_float4(p.cxx, p.cxy, p.cyy, radius);
+    a.radii[idx] = (int)radius;
+    a.tiles_touched[idx] = (uint32_t)ntile;
+}
+
+int launch_preprocess_forward(const mgs_camera& cam, int P, const float* means3D, const float* shs,
+                              const float* colors_precomp, const float* opacities, const float* scales,
+                              const float* rotations, const float* cov3D_precomp, const GeometryState& g,
+                              int32_t* radii, hipStream_t s) {
+    PreArgs a;
+    a.means3D = means3D; a.shs = shs; a.colors = colors_precomp; a.opacities = opacities;
+    a.scales = scales; a.rotations = rotations; a.cov3D = cov3D_precomp;
+    a.V = cam.viewmatrix; a.PM = cam.projmatrix; a.campos = cam.campos;
+    a.rec = g.rec; a.tiles_touched = g.tiles_touched; a.clamped = g.clamped; a.radii = radii;
+    a.tanfovx = cam.tanfovx; a.tanfovy = cam.tanfovy;
+    a.focal_x = (float)cam.image_width / (2.0f * cam.tanfovx);
+    a.focal_y = (float)cam.image_height / (2.0f * cam.tanfovy);
+    a.mod = cam.scale_modifier;
+    a.P = P; a.W = cam.image_width; a.H = cam.image_height;
+    a.gx = tiles_x(a.W); a.gy = tiles_y(a.H); a.deg = cam.sh_degree; a.M = cam.sh_coeffs;
+    if (P == 0) return 0;
+    hipLaunchKernelGGL(preprocess_forward_kernel, dim3((P + 255) / 256), dim3(256), 0, s, a);
+    MGS_HIP(hipGetLastError());
+    return 0;
+}
+
+// =================================================================================================
+// backward
+// =================================================================================================
+struct BwdArgs {
+    GeomBackwardArgs g;
+    const float *V, *PM, *PR, *campos;
+    const float* rec;
+    const uint8_t* clamped;
+    float tanfovx, tanfovy, focal_x, focal_y, mod;
+    int P, W, H, deg, M;
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__global__ void __launch_bounds__(256) geom_backward_kernel(BwdArgs a) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    float tau[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const bool live = idx < a.P && a.g.radii[idx] > 0;
+    if (idx < a.P) {
+        // defaults for culled Gaussians: every gradient is zero
+        if (a.g.dL_dmeans2D) { a.g.dL_dmeans2D[3 * idx] = 0.f; a.g.dL_dmeans2D[3 * idx + 1] = 0.f; a.g.dL_dmeans2D[3 * idx + 2] = 0.f; }
+        if (!live) {
+            if (a.g.dL_dcolors) { a.g.dL_dcolors[3 * idx] = 0.f; a.g.dL_dcolors[3 * idx + 1] = 0.f; a.g.dL_dcolors[3 * idx + 2] = 0.f; }
+            if (a.g.dL_dopacity) a.g.dL_dopacity[idx] = 0.f;
+            if (a.g.dL_dmeans3D) { a.g.dL_dmeans3D[3 * idx] = 0.f; a.g.dL_dmeans3D[3 * idx + 1] = 0.f; a.g.dL_dmeans3D[3 * idx + 2] = 0.f; }
+            if (a.g.dL_dcov3D) for (int k = 0; k < 6; ++k) a.g.dL_dcov3D[6 * idx + k] = 0.f;
+            if (a.g.dL_dscales) { a.g.dL_dscales[3 * idx] = 0.f; a.g.dL_dscales[3 * idx + 1] = 0.f; a.g.dL_dscales[3 * idx + 2] = 0.f; }
+            if (a.g.dL_drotations) for (int k = 0; k < 4; ++k) a.g.dL_drotations[4 * idx + k] = 0.f;
+            if (a.g.dL_dsh) for (int k = 0; k < a.M * 3; ++k) a.g.dL_dsh[(size_t)idx * a.M * 3 + k] = 0.f;
+        }
+    }
+    if (live) {
+        Cam c;
+        load_cam(c, a.V, a.PM, a.PR, a.campos);
+        c.tanfovx = a.tanfovx; c.tanfovy = a.tanfovy; c.focal_x = a.focal_x; c.focal_y = a.focal_y;
+        const float* ga = a.g.grad_acc + (size_t)idx * GRAD_FLOATS;
+        const float x = a.g.means3D[3 * idx], y = a.g.means3D[3 * idx + 1], z = a.g.means3D[3 * idx + 2];
+        float pv[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) pv[k] = dot3p(c.V[k], c.V[4 + k], c.V[8 + k], c.V[12 + k], x, y, z);
+
+        float cov[6], Mm[9];
+        float s[3] = {0, 0, 0}, q[4] = {1, 0, 0, 0};
+        if (a.g.cov3D_precomp) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) cov[k] = a.g.cov3D_precomp[6 * idx + k];
+        } else {
+            s[0] = a.g.scales[3 * idx]; s[1] = a.g.scales[3 * idx + 1]; s[2] = a.g.scales[3 * idx + 2];
+            q[0] = a.g.rotations[4 * idx]; q[1] = a.g.rotations[4 * idx + 1];
+            q[2] = a.g.rotations[4 * idx + 2]; q[3] = a.g.rotations[4 * idx + 3];
+            cov3d_from_scale_rot(s, q, a.mod, cov, Mm);
+        }
+        Proj p;
+        project_cov(c, pv, cov, p);
+
+        // ---- conic -> 2-D covariance.  Q = C^-1;  dL/dC = -Q G Q with G the symmetric matrix
+        //      [[gA, gB/2],[gB/2, gC]] (gB is the derivative w.r.t. the scalar b of power = -a dx^2/2 - c dy^2/2 - b dx dy)
+        const float4 r1 = reinterpret_cast<const float4*>(a.rec + (size_t)idx * REC_FLOATS)[1];
+        const float qa = r1.x, qb = r1.y, qc = r1.z;
+        const float gA = ga[G_DCA], gBh = 0.5f * ga[G_DCB], gC = ga[G_DCC];
+        // N = G Q
+        const float n00 = gA * qa + gBh * qb, n01 = gA * qb + gBh * qc;
+        const float n10 = gBh * qa + gC * qb, n11 = gBh * qb + gC * qc;
+        // Mc = -Q N  (symmetric)
+        const float m00 = -(qa * n00 + qb * n10);
+        const float m01 = -(qa * n01 + qb * n11);
+        const float m11 = -(qb * n01 + qc * n11);
+
+        // ---- C = T S T^T (+0.3 I):  dL/dS = T^T Mc T,  dL/dT = 2 Mc T S
+        float A0[3], A1[3];                                   // A = Mc T  (2x3)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            A0[j] = m00 * p.T0[j] + m01 * p.T1[j];
+            A1[j] = m01 * p.T0[j] + m11 * p.T1[j];
+        }
+        float Gs[3][3];                                       // full symmetric gradient w.r.t. Sigma
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) Gs[i][j] = p.T0[i] * A0[j] + p.T1[i] * A1[j];
+        const float S[3][3] = {{cov[0], cov[1], cov[2]}, {cov[1], cov[3], cov[4]}, {cov[2], cov[4], cov[5]}};
+        float dT0[3], dT1[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            dT0[j] = 2.f * ((A0[0] * S[0][j] + A0[1] * S[1][j]) + A0[2] * S[2][j]);
+            dT1[j] = 2.f * ((A1[0] * S[0][j] + A1[1] * S[1][j]) + A1[2] * S[2][j]);
+        }
+        // ---- T = J Rv:  dL/dJ = dT Rv^T,  dL/dRv = J^T dT
+        const float dJ00 = (dT0[0] * c.V[0] + dT0[1] * c.V[4]) + dT0[2] * c.V[8];     // row 0 of Rv
+        const float dJ02 = (dT0[0] * c.V[2] + dT0[1] * c.V[6]) + dT0[2] * c.V[10];    // row 2 of Rv
+        const float dJ11 = (dT1[0] * c.V[1] + dT1[1] * c.V[5]) + dT1[2] * c.V[9];     // row 1
+        const float dJ12 = (dT1[0] * c.V[2] + dT1[1] * c.V[6]) + dT1[2] * c.V[10];
+        float dRv[3][3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            dRv[0][j] = p.J00 * dT0[j];
+            dRv[1][j] = p.J11 * dT1[j];
+            dRv[2][j] = p.J02 * dT0[j] + p.J12 * dT1[j];
+        }
+        const float tz = p.tz, itz = 1.f / tz, itz2 = itz * itz, itz3 = itz2 * itz;
+        float gpc[3];   // dL/d p_c, accumulated over the covariance, mean and depth paths
+        gpc[0] = p.clamp_x ? 0.f : -c.focal_x * itz2 * dJ02;
+        gpc[1] = p.clamp_y ? 0.f : -c.focal_y * itz2 * dJ12;
+        gpc[2] = -c.focal_x * itz2 * dJ00 - c.focal_y * itz2 * dJ11 + 2.f * c.focal_x * p.tx * itz3 * dJ02 +
+                 2.f * c.focal_y * p.ty * itz3 * dJ12;
+
+        // ---- pixel mean:  pix = ((ndc + 1) S - 1)/2,  ndc = ph.xy / (ph.w + 1e-7),  ph = P_raw [p_c; 1]
+        const float gpx = ga[G_DX], gpy = ga[G_DY];
+        const float gnx = gpx * 0.5f * (float)a.W, gny = gpy * 0.5f * (float)a.H;
+        if (a.g.dL_dmeans2D) { a.g.dL_dmeans2D[3 * idx] = gnx; a.g.dL_dmeans2D[3 * idx + 1] = gny; }
+        float ph[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ph[k] = dot3p(c.PM[k], c.PM[4 + k], c.PM[8 + k], c.PM[12 + k], x, y, z);
+        const float p_w = 1.0f / (ph[3] + 0.0000001f);
+        const float dph[4] = {gnx * p_w, gny * p_w, 0.f, -(gnx * ph[0] + gny * ph[1]) * p_w * p_w};
+#pragma unroll
+        for (int j = 0; j < 3; ++j)     // dL/dp_c[j] += sum_k dph[k] * Praw(k,j),  Praw(k,j) = PR[4*j+k]
+            gpc[j] += ((dph[0] * c.PR[4 * j] + dph[1] * c.PR[4 * j + 1]) + dph[2] * c.PR[4 * j + 2]) +
+                      dph[3] * c.PR[4 * j + 3];
+        // ---- depth = p_c.z
+        gpc[2] += ga[G_DDEPTH];
+
+        // ---- colour
+        float gmean_w[3] = {0.f, 0.f, 0.f};   // direct world-space contributions (SH view direction)
+        if (a.g.colors_precomp) {
+            if (a.g.dL_dcolors) {
+                a.g.dL_dcolors[3 * idx] = ga[G_DR]; a.g.dL_dcolors[3 * idx + 1] = ga[G_DG]; a.g.dL_dcolors[3 * idx + 2] = ga[G_DB];
+            }
+        } else {
+            float gc[3] = {ga[G_DR], ga[G_DG], ga[G_DB]};
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) if (a.clamped[4 * idx + ch]) gc[ch] = 0.f;
+            float dv[3] = {x - c.campos[0], y - c.campos[1], z - c.campos[2]};
+            const float len2 = (dv[0] * dv[0] + dv[1] * dv[1]) + dv[2] * dv[2];
+            const float len = sqrtf(len2), ilen = 1.f / len;
+            const float dx = dv[0] * ilen, dy = dv[1] * ilen, dz = dv[2] * ilen;
+            const float* sh = a.g.shs + (size_t)idx * a.M * 3;
+            float* dsh = a.g.dL_dsh ? a.g.dL_dsh + (size_t)idx * a.M * 3 : nullptr;
+            float gdir[3] = {0.f, 0.f, 0.f};
+            const int deg = a.deg;
+            if (dsh) for (int k = (deg + 1) * (deg + 1) * 3; k < a.M * 3; ++k) dsh[k] = 0.f;
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                const float g = gc[ch];
+                if (dsh) dsh[ch] = SH_C0 * g;
+                if (deg > 0) {
+                    if (dsh) { dsh[3 + ch] = -SH_C1 * dy * g; dsh[6 + ch] = SH_C1 * dz * g; dsh[9 + ch] = -SH_C1 * dx * g; }
+                    float gx_ = -SH_C1 * sh[9 + ch], gy_ = -SH_C1 * sh[3 + ch], gz_ = SH_C1 * sh[6 + ch];
+                    if (deg > 1) {
+                        const float xx = dx * dx, yy = dy * dy, zz = dz * dz, xy = dx * dy, yz = dy * dz, xz = dx * dz;
+                        if (dsh) {
+                            dsh[12 + ch] = SH_C2[0] * xy * g; dsh[15 + ch] = SH_C2[1] * yz * g;
+                            dsh[18 + ch] = SH_C2[2] * (2.f * zz - xx - yy) * g;
+                            dsh[21 + ch] = SH_C2[3] * xz * g; dsh[24 + ch] = SH_C2[4] * (xx - yy) * g;
+                        }
+                        gx_ += SH_C2[0] * dy * sh[12 + ch] + SH_C2[2] * 2.f * -dx * sh[18 + ch] + SH_C2[3] * dz * sh[21 + ch] + SH_C2[4] * 2.f * dx * sh[24 + ch];
+                        gy_ += SH_C2[0] * dx * sh[12 + ch] + SH_C2[1] * dz * sh[15 + ch] + SH_C2[2] * 2.f * -dy * sh[18 + ch] + SH_C2[4] * 2.f * -dy * sh[24 + ch];
+                        gz_ += SH_C2[1] * dy * sh[15 + ch] + SH_C2[2] * 2.f * 2.f * dz * sh[18 + ch] + SH_C2[3] * dx * sh[21 + ch];
+                        if (deg > 2) {
+                            if (dsh) {
+                                dsh[27 + ch] = SH_C3[0] * dy * (3.f * xx - yy) * g; dsh[30 + ch] = SH_C3[1] * xy * dz * g;
+                                dsh[33 + ch] = SH_C3[2] * dy * (4.f * zz - xx - yy) * g;
+                                dsh[36 + ch] = SH_C3[3] * dz * (2.f * zz - 3.f * xx - 3.f * yy) * g;
+                                dsh[39 + ch] = SH_C3[4] * dx * (4.f * zz - xx - yy) * g;
+                                dsh[42 + ch] = SH_C3[5] * dz * (xx - yy) * g; dsh[45 + ch] = SH_C3[6] * dx * (xx - 3.f * yy) * g;
+                            }
+                            gx_ += SH_C3[0] * sh[27 + ch] * 3.f * 2.f * xy + SH_C3[1] * sh[30 + ch] * yz +
+                                   SH_C3[2] * sh[33 + ch] * -2.f * xy + SH_C3[3] * sh[36 + ch] * -3.f * 2.f * xz +
+                                   SH_C3[4] * sh[39 + ch] * (-3.f * xx + 4.f * zz - yy) + SH_C3[5] * sh[42 + ch] * 2.f * xz +
+                                   SH_C3[6] * sh[45 + ch] * 3.f * (xx - yy);
+                            gy_ += SH_C3[0] * sh[27 + ch] * 3.f * (xx - yy) + SH_C3[1] * sh[30 + ch] * xz +
+                                   SH_C3[2] * sh[33 + ch] * (-3.f * yy + 4.f * zz - xx) + SH_C3[3] * sh[36 + ch] * -3.f * 2.f * yz +
+                                   SH_C3[4] * sh[39 + ch] * -2.f * xy + SH_C3[5] * sh[42 + ch] * -2.f * yz +
+                                   SH_C3[6] * sh[45 + ch] * -3.f * 2.f * xy;
+                            gz_ += SH_C3[1] * sh[30 + ch] * xy + SH_C3[2] * sh[33 + ch] * 4.f * 2.f * yz +
+                                   SH_C3[3] * sh[36 + ch] * 3.f * (2.f * zz - xx - yy) + SH_C3[4] * sh[39 + ch] * 4.f * 2.f * xz +
+                                   SH_C3[5] * sh[42 + ch] * (xx - yy);
+                        }
+                    }
+                    gdir[0] += gx_ * g; gdir[1] += gy_ * g; gdir[2] += gz_ * g;
+                }
+            }
+            // through the normalisation d = v/|v|:  dL/dv = (g - d (d.g)) / |v|
+            const float dg = (dx * gdir[0] + dy * gdir[1]) + dz * gdir[2];
+            gmean_w[0] = (gdir[0] - dx * dg) * ilen;
+            gmean_w[1] = (gdir[1] - dy * dg) * ilen;
+            gmean_w[2] = (gdir[2] - dz * dg) * ilen;
+            // campos = -R^T (t + rho) to first order  =>  dL/drho += R gmean_w   (dL/dcampos = -gmean_w)
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                tau[i] += (c.V[i] * gmean_w[0] + c.V[4 + i] * gmean_w[1]) + c.V[8 + i] * gmean_w[2];
+        }
+        if (a.g.dL_dopacity) a.g.dL_dopacity[idx] = ga[G_DOP];
+
+        // ---- world-space mean:  p_c = Rv p + t
+        if (a.g.dL_dmeans3D) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j)   // (Rv^T gpc)[j] = sum_i Rv(i,j) gpc[i],  Rv(i,j) = V[4*j+i]
+                a.g.dL_dmeans3D[3 * idx + j] =
+                    ((c.V[4 * j] * gpc[0] + c.V[4 * j + 1] * gpc[1]) + c.V[4 * j + 2] * gpc[2]) + gmean_w[j];
+        }
+        // ---- pose:  d p_c / d rho = I,  d p_c / d theta = -[p_c]x,  d Rv(:,j) / d theta = -[Rv(:,j)]x
+        tau[0] += gpc[0]; tau[1] += gpc[1]; tau[2] += gpc[2];
+        tau[3] += pv[1] * gpc[2] - pv[2] * gpc[1];
+        tau[4] += pv[2] * gpc[0] - pv[0] * gpc[2];
+        tau[5] += pv[0] * gpc[1] - pv[1] * gpc[0];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const float r0 = c.V[4 * j], r1_ = c.V[4 * j + 1], r2 = c.V[4 * j + 2];   // column j of Rv
+            tau[3] += r1_ * dRv[2][j] - r2 * dRv[1][j];
+            tau[4] += r2 * dRv[0][j] - r0 * dRv[2][j];
+            tau[5] += r0 * dRv[1][j] - r1_ * dRv[0][j];
+        }
+
+        // ---- Sigma = M M^T, M = R diag(mod*s)
+        if (a.g.cov3D_precomp) {
+            if (a.g.dL_dcov3D) {
+                float* o = a.g.dL_dcov3D + 6 * idx;
+                o[0] = Gs[0][0]; o[1] = 2.f * Gs[0][1]; o[2] = 2.f * Gs[0][2];
+                o[3] = Gs[1][1]; o[4] = 2.f * Gs[1][2]; o[5] = Gs[2][2];
+            }
+        } else {
+            float dM[9];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    dM[3 * i + j] = 2.f * ((Gs[i][0] * Mm[j] + Gs[i][1] * Mm[3 + j]) + Gs[i][2] * Mm[6 + j]);
+            const float r = q[0], qx = q[1], qy = q[2], qz = q[3];
+            const float Rm[9] = {1.f - 2.f * (qy * qy + qz * qz), 2.f * (qx * qy - r * qz), 2.f * (qx * qz + r * qy),
+                                 2.f * (qx * qy + r * qz), 1.f - 2.f * (qx * qx + qz * qz), 2.f * (qy * qz - r * qx),
+                                 2.f * (qx * qz - r * qy), 2.f * (qy * qz + r * qx), 1.f - 2.f * (qx * qx + qy * qy)};
+            const float sm[3] = {s[0] * a.mod, s[1] * a.mod, s[2] * a.mod};
+            if (a.g.dL_dscales) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    a.g.dL_dscales[3 * idx + j] =
+                        a.mod * ((dM[j] * Rm[j] + dM[3 + j] * Rm[3 + j]) + dM[6 + j] * Rm[6 + j]);
+            }
+            if (a.g.dL_drotations) {
+                float dR[9];
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) dR[3 * i + j] = dM[3 * i + j] * sm[j];
+                // derivative of the (unnormalised) quaternion -> matrix map above
+                const float dr = 2.f * (qz * (dR[3] - dR[1]) + qy * (dR[2] - dR[6]) + qx * (dR[7] - dR[5]));
+                const float dqx = 2.f * (qy * (dR[1] + dR[3]) + qz * (dR[2] + dR[6]) + r * (dR[7] - dR[5])) -
+                                  4.f * qx * (dR[4] + dR[8]);
+                const float dqy = 2.f * (qx * (dR[1] + dR[3]) + r * (dR[2] - dR[6]) + qz * (dR[5] + dR[7])) -
+                                  4.f * qy * (dR[0] + dR[8]);
+                const float dqz = 2.f * (r * (dR[3] - dR[1]) + qx * (dR[2] + dR[6]) + qy * (dR[5] + dR[7])) -
+                                  4.f * qz * (dR[0] + dR[4]);
+                float* o = a.g.dL_drotations + 4 * idx;
+                o[0] = dr; o[1] = dqx; o[2] = dqy; o[3] = dqz;
+            }
+        }
+    }
+    // ---- block reduction of the 6 pose components, one atomic per block and component
+    if (a.g.dL_dtau) {
+        __shared__ float part[4][6];
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const float v = wave_sum(tau[k]);
+            if (lane == 0) part[wv][k] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x < 6) {
+            const float v = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+            if (v != 0.f) atomicAdd(a.g.dL_dtau + threadIdx.x, v);
+        }
+    }
+}
+
+int launch_geom_backward(const mgs_camera& cam, int P, const GeometryState& g, const GeomBackwardArgs& ga,
+                         hipStream_t s) {
+    BwdArgs a;
+    a.g = ga;
+    a.V = cam.viewmatrix; a.PM = cam.projmatrix; a.PR = cam.projmatrix_raw; a.campos = cam.campos;
+    a.rec = g.rec; a.clamped = g.clamped;
+    a.tanfovx = cam.tanfovx; a.tanfovy = cam.tanfovy;
+    a.focal_x = (float)cam.image_width / (2.0f * cam.tanfovx);
+    a.focal_y = (float)cam.image_height / (2.0f * cam.tanfovy);
+    a.mod = cam.scale_modifier;
+    a.P = P; a.W = cam.image_width; a.H = cam.image_height; a.deg = cam.sh_degree; a.M = cam.sh_coeffs;
+    if (ga.dL_dtau) MGS_HIP(hipMemsetAsync(ga.dL_dtau, 0, 6 * sizeof(float), s));
+    if (P == 0) return 0;
+    hipLaunchKernelGGL(geom_backward_kernel, dim3((P + 255) / 256), dim3(256), 0, s, a);
+    MGS_HIP(hipGetLastError());
+    return 0;
+}
+
+// =================================================================================================
+__global__ void mark_visible_kernel(int P, const float* means3D, const float* V, uint8_t* visible) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= P) return;
+    const float x = means3D[3 * idx], y = means3D[3 * idx + 1], z = means3D[3 * idx + 2];
+    const float vz = dot3p(V[2], V[6], V[10], V[14], x, y, z);
+    visible[idx] = vz > 0.2f;
+}
+
+int launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* visible, hipStream_t s) {
+    if (P == 0) return 0;
+    hipLaunchKernelGGL(mark_visible_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, means3D, viewmatrix, visible);
+    MGS_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace mgs

@@ -1,0 +1,68 @@
+"""Test/diagnostic access to the binning tables the forward leaves in its scratch buffers.
+Calls the C ABI directly (include/monogs_raster.h) and decodes the documented scratch layout
+(256-byte aligned sub-buffers in declaration order, see csrc/api.hip)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .rasterizer import _camera, _f32, _ptr, _stream
+
+
+def _au(v, a=256):
+    return (v + a - 1) // a * a
+
+
+def forward_tables(rs, means3D, opacities, colors_precomp=None, shs=None, scales=None, rotations=None,
+                   cov3D_precomp=None):
+    """Run the HIP forward and return outputs plus the per-tile tables as torch tensors."""
+    lib = _lib.load()
+    dev = means3D.device
+    P = means3D.shape[0]
+    H, W = int(rs.image_height), int(rs.image_width)
+    c = lambda t, n: None if t is None else _f32(t.detach(), n)  # noqa: E731
+    means3D, opacities = c(means3D, "means3D"), c(opacities, "opacities")
+    colors_precomp, shs, scales = c(colors_precomp, "colors"), c(shs, "shs"), c(scales, "scales")
+    rotations, cov3D_precomp = c(rotations, "rotations"), c(cov3D_precomp, "cov3D")
+    with torch.cuda.device(dev):
+        keep = []
+        cam = _camera(rs, 0 if shs is None else shs.shape[1], keep)
+        u8 = dict(dtype=torch.uint8, device=dev)
+        geom = torch.zeros(lib.mgs_geometry_bytes(P), **u8)
+        img = torch.zeros(lib.mgs_image_bytes(W, H), **u8)
+        radii = torch.empty(P, dtype=torch.int32, device=dev)
+        n_touched = torch.empty(P, dtype=torch.int32, device=dev)
+        color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
+        depth = torch.empty(1, H, W, dtype=torch.float32, device=dev)
+        opacity = torch.empty(1, H, W, dtype=torch.float32, device=dev)
+        nr = C.c_uint64(0)
+        _lib.check(lib.mgs_forward_preprocess(C.byref(cam), P, _ptr(means3D), _ptr(shs), _ptr(colors_precomp),
+                                              _ptr(opacities), _ptr(scales), _ptr(rotations), _ptr(cov3D_precomp),
+                                              geom.data_ptr(), radii.data_ptr(), C.byref(nr), None, _stream()),
+                   "mgs_forward_preprocess")
+        R = int(nr.value)
+        binning = torch.zeros(lib.mgs_binning_bytes(R, W, H), **u8)
+        _lib.check(lib.mgs_forward_render(C.byref(cam), P, R, geom.data_ptr(), binning.data_ptr(), img.data_ptr(),
+                                          color.data_ptr(), depth.data_ptr(), opacity.data_ptr(),
+                                          n_touched.data_ptr(), None, _stream()), "mgs_forward_render")
+        torch.cuda.synchronize()
+
+    def view(buf, off, nbytes, dtype):
+        base = _au(buf.data_ptr()) - buf.data_ptr()
+        return buf[base + off: base + off + nbytes].view(dtype)
+
+    HW = H * W
+    ntiles = ((W + 15) // 16) * ((H + 15) // 16)
+    final_T = view(img, 0, HW * 4, torch.float32).reshape(H, W)
+    n_contrib = view(img, _au(HW * 4), HW * 4, torch.int32).reshape(H, W)
+    ranges = view(img, 2 * _au(HW * 4), ntiles * 8, torch.int32).reshape(ntiles, 2)
+    r = max(R, 1)
+    keys_sorted = view(binning, _au(r * 8), R * 8, torch.int64)
+    point_list = view(binning, 2 * _au(r * 8) + _au(r * 4), R * 4, torch.int32)
+    rec = view(geom, 0, P * 64, torch.float32).reshape(P, 16)
+    tiles_touched = view(geom, _au(P * 64), P * 4, torch.int32)
+    return dict(color=color, depth=depth, opacity=opacity, radii=radii, n_touched=n_touched, num_rendered=R,
+                final_T=final_T, n_contrib=n_contrib, ranges=ranges, keys_sorted=keys_sorted,
+                point_list=point_list, rec=rec, tiles_touched=tiles_touched)

@@ -1,0 +1,229 @@
+"""``GaussianRasterizationSettings`` / ``GaussianRasterizer`` -- host side of the drop-in.
+
+Mirrors the Python surface of the un-vendored ``diff_gaussian_rasterization`` (w-pose variant)
+exactly as MonoGS uses it: settings built at
+/root/reference/gaussian_splatting/gaussian_renderer/__init__.py:70-84, rasteriser called by
+keyword at :130-156, outputs consumed at :160-168.  The arithmetic lives in
+libmonogs_raster.so (HIP, gfx950) behind the C ABI of include/monogs_raster.h; torch is used
+for device memory, the current stream and autograd plumbing only.
+"""
+from __future__ import annotations
+
+import contextlib
+import ctypes as C
+from typing import NamedTuple, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    projmatrix_raw: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+# ---- optional per-stage timing (bench.py) --------------------------------------------------
+_timing_sink: Optional[list] = None
+
+
+@contextlib.contextmanager
+def collect_timing():
+    """Within the block every forward/backward appends a dict of per-stage device milliseconds
+    (HIP events on the launch stream, see mgs_timing) to the yielded list.  Synchronises."""
+    global _timing_sink
+    prev, _timing_sink = _timing_sink, []
+    try:
+        yield _timing_sink
+    finally:
+        _timing_sink = prev
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _f32(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA/HIP tensor (got device {t.device}); "
+                           "the rasteriser has no CPU path")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{name} must be float32 (got {t.dtype})")
+    return t.contiguous()
+
+
+def _camera(rs: GaussianRasterizationSettings, sh_coeffs: int, keep: list) -> _lib.MgsCamera:
+    cam = _lib.MgsCamera()
+    cam.image_height, cam.image_width = int(rs.image_height), int(rs.image_width)
+    cam.tanfovx, cam.tanfovy = float(rs.tanfovx), float(rs.tanfovy)
+    cam.scale_modifier = float(rs.scale_modifier)
+    cam.sh_degree, cam.sh_coeffs = int(rs.sh_degree), int(sh_coeffs)
+    for field in ("bg", "viewmatrix", "projmatrix", "projmatrix_raw", "campos"):
+        t = _f32(getattr(rs, field).detach(), f"raster_settings.{field}")
+        keep.append(t)
+        setattr(cam, field, t.data_ptr())
+    return cam
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                theta, rho, raster_settings):
+        lib = _lib.load()
+        rs = raster_settings
+        means3D = _f32(means3D.detach(), "means3D")
+        P = means3D.shape[0]
+        dev = means3D.device
+        opt = lambda t, n: _f32(t.detach(), n) if (t is not None and t.numel() > 0) else None  # noqa: E731
+        sh_ = opt(sh, "shs")
+        col_ = opt(colors_precomp, "colors_precomp")
+        opac_ = _f32(opacities.detach(), "opacities")
+        sc_ = opt(scales, "scales")
+        rot_ = opt(rotations, "rotations")
+        cov_ = opt(cov3Ds_precomp, "cov3D_precomp")
+        M = 0 if sh_ is None else int(sh_.shape[1])
+        H, W = int(rs.image_height), int(rs.image_width)
+
+        with torch.cuda.device(dev):
+            keep = []
+            cam = _camera(rs, M, keep)
+            timing = _lib.MgsTiming() if _timing_sink is not None else None
+            tref = C.byref(timing) if timing is not None else None
+            u8 = dict(dtype=torch.uint8, device=dev)
+            geom = torch.empty(lib.mgs_geometry_bytes(P), **u8)
+            img = torch.empty(lib.mgs_image_bytes(W, H), **u8)
+            radii = torch.empty(P, dtype=torch.int32, device=dev)
+            n_touched = torch.empty(P, dtype=torch.int32, device=dev)
+            color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
+            depth = torch.empty(1, H, W, dtype=torch.float32, device=dev)
+            opacity = torch.empty(1, H, W, dtype=torch.float32, device=dev)
+            num_rendered = C.c_uint64(0)
+            _lib.check(lib.mgs_forward_preprocess(
+                C.byref(cam), P, _ptr(means3D), _ptr(sh_), _ptr(col_), _ptr(opac_), _ptr(sc_), _ptr(rot_),
+                _ptr(cov_), geom.data_ptr(), radii.data_ptr(), C.byref(num_rendered), tref, _stream()),
+                "mgs_forward_preprocess")
+            R = int(num_rendered.value)
+            binning = torch.empty(lib.mgs_binning_bytes(R, W, H), **u8)
+            _lib.check(lib.mgs_forward_render(
+                C.byref(cam), P, R, geom.data_ptr(), binning.data_ptr(), img.data_ptr(), color.data_ptr(),
+                depth.data_ptr(), opacity.data_ptr(), n_touched.data_ptr(), tref, _stream()),
+                "mgs_forward_render")
+            if timing is not None:
+                d = timing.as_dict()
+                d.update(kind="forward", num_rendered=R, P=P)
+                _timing_sink.append(d)
+
+        ctx.raster_settings = rs
+        ctx.num_rendered = R
+        ctx.sh_coeffs = M
+        ctx.has = (sh_ is not None, col_ is not None, sc_ is not None, cov_ is not None,
+                   theta is not None, rho is not None)
+        dummy = torch.empty(0, device=dev)
+        ctx.save_for_backward(means3D, sh_ if sh_ is not None else dummy, col_ if col_ is not None else dummy,
+                              opac_, sc_ if sc_ is not None else dummy, rot_ if rot_ is not None else dummy,
+                              cov_ if cov_ is not None else dummy, radii, geom, binning, img)
+        ctx.mark_non_differentiable(radii, n_touched)
+        return color, radii, depth, opacity, n_touched
+
+    @staticmethod
+    def backward(ctx, grad_color, grad_radii, grad_depth, grad_opacity, grad_n_touched):
+        # grad_opacity is ignored, as upstream does
+        lib = _lib.load()
+        rs = ctx.raster_settings
+        means3D, sh_, col_, opac_, sc_, rot_, cov_, radii, geom, binning, img = ctx.saved_tensors
+        has_sh, has_col, has_sr, has_cov, has_theta, has_rho = ctx.has
+        P = means3D.shape[0]
+        dev = means3D.device
+        H, W = int(rs.image_height), int(rs.image_width)
+        need = ctx.needs_input_grad   # means3D, means2D, sh, colors, opacities, scales, rotations, cov3D, theta, rho
+
+        with torch.cuda.device(dev):
+            keep = []
+            cam = _camera(rs, ctx.sh_coeffs, keep)
+            f32 = dict(dtype=torch.float32, device=dev)
+            g_color = _f32(grad_color, "grad_color") if grad_color is not None else torch.zeros(3, H, W, **f32)
+            g_depth = _f32(grad_depth, "grad_depth") if grad_depth is not None else torch.zeros(1, H, W, **f32)
+            out = lambda cond, *shape: torch.empty(*shape, **f32) if cond else None  # noqa: E731
+            d_means3D = out(need[0], P, 3)
+            d_means2D = out(need[1], P, 3)
+            d_sh = out(need[2] and has_sh, P, max(ctx.sh_coeffs, 1), 3)
+            d_col = out(need[3] and has_col, P, 3)
+            d_opac = out(need[4], P, 1)
+            d_scales = out(need[5] and has_sr, P, 3)
+            d_rot = out(need[6] and has_sr, P, 4)
+            d_cov = out(need[7] and has_cov, P, 6)
+            want_tau = (need[8] and has_theta) or (need[9] and has_rho)
+            d_tau = torch.empty(6, **f32) if want_tau else None
+            scratch = torch.empty(lib.mgs_backward_bytes(P), dtype=torch.uint8, device=dev)
+            timing = _lib.MgsTiming() if _timing_sink is not None else None
+            tref = C.byref(timing) if timing is not None else None
+            _lib.check(lib.mgs_backward(
+                C.byref(cam), P, ctx.num_rendered,
+                _ptr(means3D), _ptr(sh_) if has_sh else None, _ptr(col_) if has_col else None, _ptr(opac_),
+                _ptr(sc_) if has_sr else None, _ptr(rot_) if has_sr else None, _ptr(cov_) if has_cov else None,
+                radii.data_ptr(), geom.data_ptr(), binning.data_ptr(), img.data_ptr(),
+                g_color.data_ptr(), g_depth.data_ptr(),
+                _ptr(d_means2D), _ptr(d_col), _ptr(d_opac), _ptr(d_means3D), _ptr(d_cov), _ptr(d_sh),
+                _ptr(d_scales), _ptr(d_rot), _ptr(d_tau), scratch.data_ptr(), tref, _stream()),
+                "mgs_backward")
+            if timing is not None:
+                d = timing.as_dict()
+                d.update(kind="backward", num_rendered=ctx.num_rendered, P=P)
+                _timing_sink.append(d)
+        d_theta = d_tau[3:].clone() if (d_tau is not None and need[8] and has_theta) else None
+        d_rho = d_tau[:3].clone() if (d_tau is not None and need[9] and has_rho) else None
+        return (d_means3D, d_means2D, d_sh, d_col, d_opac, d_scales, d_rot, d_cov, d_theta, d_rho, None)
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                        theta, rho, raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                     cov3Ds_precomp, theta, rho, raster_settings)
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings: GaussianRasterizationSettings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions: torch.Tensor) -> torch.Tensor:
+        """bool[P]: inside the view frustum's near side (view-space z > 0.2)."""
+        lib = _lib.load()
+        rs = self.raster_settings
+        with torch.no_grad():
+            pos = _f32(positions, "positions")
+            P = pos.shape[0]
+            vis = torch.zeros(P, dtype=torch.uint8, device=pos.device)
+            with torch.cuda.device(pos.device):
+                vm = _f32(rs.viewmatrix, "viewmatrix")
+                pm = _f32(rs.projmatrix, "projmatrix")
+                _lib.check(lib.mgs_mark_visible(P, pos.data_ptr(), vm.data_ptr(), pm.data_ptr(), vis.data_ptr(),
+                                                _stream()), "mgs_mark_visible")
+        return vis.bool()
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None, theta=None, rho=None):
+        rs = self.raster_settings
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception("Please provide excatly one of either SHs or precomputed colors!")
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
+                                   cov3D_precomp, theta, rho, rs)

@@ -1,0 +1,145 @@
+"""HIP path vs the CPU oracle on seeded scenes (run on the MI355X box: pytest -m gpu).
+
+Bars (BASELINE.json north_star): tile ranges / radii / blend order bit-exact; pixel Linf <= 1e-4;
+gradient rtol <= 1e-3.  Pixels whose blend contains a decision within a few float32 ulps of its
+threshold (alpha vs 1/255, T vs 1e-4 / 0.5) are reported and exempted from the pixel bar: a
+different but equally valid exp rounding flips them, upstream included.
+"""
+import pytest
+import torch
+
+from monogs_amd.synthetic import make_scene, scene_settings
+from oracle import OracleSettings, rasterize, rasterize_autograd
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _hip_settings(sc):
+    from monogs_amd.rasterizer import GaussianRasterizationSettings
+    return scene_settings(sc, GaussianRasterizationSettings, device=DEV)
+
+
+def _inputs(sc, aniso=False):
+    scales = sc.scales if sc.scales.shape[1] == 3 else sc.scales.repeat(1, 3)
+    return dict(means3D=sc.means3D, opacities=sc.opacities, colors_precomp=sc.colors, scales=scales,
+                rotations=sc.rotations)
+
+
+def _run_hip(sc, inp, st):
+    from monogs_amd.rasterizer import GaussianRasterizer
+    leaves = {k: v.to(DEV).clone().requires_grad_(True) for k, v in inp.items()}
+    means2D = torch.zeros_like(leaves["means3D"], requires_grad=True)
+    theta = torch.zeros(3, device=DEV, requires_grad=True)
+    rho = torch.zeros(3, device=DEV, requires_grad=True)
+    out = GaussianRasterizer(st)(means3D=leaves["means3D"], means2D=means2D, opacities=leaves["opacities"],
+                                 shs=leaves.get("shs"), colors_precomp=leaves.get("colors_precomp"),
+                                 scales=leaves.get("scales"), rotations=leaves.get("rotations"),
+                                 cov3D_precomp=leaves.get("cov3D_precomp"), theta=theta, rho=rho)
+    color, radii, depth, opacity, n_touched = out
+    loss = (color * sc.grad_color.to(DEV)).sum() + (depth * sc.grad_depth.to(DEV)).sum()
+    loss.backward()
+    grads = {k: v.grad.cpu() for k, v in leaves.items()}
+    grads.update(means2D=means2D.grad.cpu(), theta=theta.grad.cpu(), rho=rho.grad.cpu())
+    return [o.detach().cpu() for o in out], grads
+
+
+def _check_grads(grads, ograds, rtol=1e-3, max_outlier_frac=2e-4):
+    report = {}
+    for k, ref in ograds.items():
+        got = grads[k].reshape(ref.shape).double()
+        ref = ref.double()
+        scale = ref.abs().max().item()
+        if scale == 0:
+            assert got.abs().max().item() == 0, k
+            continue
+        rel_l2 = ((got - ref).norm() / ref.norm()).item()
+        bad = ((got - ref).abs() > rtol * ref.abs() + 1e-4 * scale)
+        report[k] = (rel_l2, bad.float().mean().item())
+        assert rel_l2 <= rtol, f"{k}: relative L2 error {rel_l2:.3e}"
+        assert bad.float().mean().item() <= max_outlier_frac, f"{k}: {bad.sum().item()} elements off"
+    return report
+
+
+@pytest.mark.parametrize("P,intr,seed,aniso", [(5000, "fr3_office", 0, False), (3000, "fr3_office", 5, True),
+                                               (20000, "replica", 7, False)])
+def test_forward_tables_bit_exact(native_lib, P, intr, seed, aniso):
+    from monogs_amd.debug import forward_tables
+    sc = make_scene(P, intr, seed=seed, anisotropic=aniso)
+    inp = _inputs(sc)
+    o = rasterize(sc.means3D, None, sc.opacities, scene_settings(sc, OracleSettings),
+                  colors_precomp=sc.colors, scales=inp["scales"], rotations=sc.rotations, want_ambiguous=True)
+    t = forward_tables(_hip_settings(sc), sc.means3D.to(DEV), sc.opacities.to(DEV),
+                       colors_precomp=sc.colors.to(DEV), scales=inp["scales"].to(DEV),
+                       rotations=sc.rotations.to(DEV))
+    assert t["num_rendered"] == o.aux["num_rendered"]
+    assert torch.equal(t["radii"].cpu(), o.radii)
+    assert torch.equal(t["tiles_touched"].cpu().long(), o.aux["geom"]["tiles_touched"])
+    assert torch.equal(t["ranges"].cpu().long(), o.aux["ranges"])
+    assert torch.equal(t["point_list"].cpu().long(), o.aux["point_list"])
+    keys = torch.from_numpy(o.aux["keys"].astype("int64"))
+    assert torch.equal(t["keys_sorted"].cpu(), keys)
+    amb = o.aux["ambiguous"]
+    ok = ~amb
+    err = (t["color"].cpu() - o.color).abs().amax(0)
+    print(f"ambiguous pixels: {int(amb.sum())} of {amb.numel()}; Linf clear {err[ok].max():.2e}, "
+          f"Linf all {err.max():.2e}")
+    assert amb.float().mean() < 1e-3
+    assert err[ok].max() <= 1e-4
+    assert (t["depth"].cpu() - o.depth).abs()[0][ok].max() <= 1e-4 * max(1.0, o.depth.max().item())
+    assert (t["opacity"].cpu() - o.opacity).abs()[0][ok].max() <= 1e-4
+    assert (t["final_T"].cpu() - o.aux["final_T"][0]).abs()[ok].max() <= 1e-4
+    nc_bad = (t["n_contrib"].cpu().long() != o.aux["n_contrib"][0])
+    assert not (nc_bad & ok).any()
+    nt_diff = (t["n_touched"].cpu() - o.n_touched).abs()
+    assert nt_diff.sum() <= 4 * amb.sum() + 2, f"n_touched differs by {nt_diff.sum()}"
+    # invariants
+    assert ((t["n_touched"] > 0) <= (t["radii"] > 0)).all()
+    assert torch.allclose(t["opacity"][0], 1 - t["final_T"], atol=1e-6)
+
+
+@pytest.mark.parametrize("P,intr,seed,aniso,bg", [(5000, "fr3_office", 0, False, (0., 0., 0.)),
+                                                  (4000, "fr3_office", 11, True, (0.3, 0.5, 0.7))])
+def test_backward_vs_oracle(native_lib, P, intr, seed, aniso, bg):
+    sc = make_scene(P, intr, seed=seed, anisotropic=aniso, bg=bg)
+    inp = _inputs(sc)
+    outs, grads = _run_hip(sc, inp, _hip_settings(sc))
+    oout, ograds = rasterize_autograd(inp, scene_settings(sc, OracleSettings), sc.grad_color, sc.grad_depth,
+                                      dtype=torch.float32, want_ambiguous=True)
+    ok = ~oout.aux["ambiguous"]
+    assert (outs[0] - oout.color).abs().amax(0)[ok].max() <= 1e-4
+    rep = _check_grads(grads, ograds)
+    print({k: (f"{a:.2e}", f"{b:.1e}") for k, (a, b) in rep.items()})
+
+
+def test_c2_100k(native_lib):
+    """BASELINE config 2: 100k Gaussians, 640x480, fwd+bwd vs the oracle."""
+    sc = make_scene(100000, "fr3_office", seed=1)
+    inp = _inputs(sc)
+    outs, grads = _run_hip(sc, inp, _hip_settings(sc))
+    oout, ograds = rasterize_autograd(inp, scene_settings(sc, OracleSettings), sc.grad_color, sc.grad_depth,
+                                      dtype=torch.float32, want_ambiguous=True)
+    amb = oout.aux["ambiguous"]
+    ok = ~amb
+    err = (outs[0] - oout.color).abs().amax(0)
+    print(f"C2: ambiguous {int(amb.sum())}; Linf clear {err[ok].max():.2e}; all {err.max():.2e}")
+    assert torch.equal(outs[1], oout.radii)
+    assert err[ok].max() <= 1e-4
+    rep = _check_grads(grads, ograds)
+    print({k: (f"{a:.2e}", f"{b:.1e}") for k, (a, b) in rep.items()})
+
+
+def test_knn(native_lib):
+    from monogs_amd.knn import distCUDA2
+    from oracle import dist2_knn
+    g = torch.Generator().manual_seed(0)
+    for P in (4, 77, 9600, 25500):
+        pts = torch.rand(P, 3, generator=g) * 4 - 2
+        got = distCUDA2(pts.to(DEV)).cpu()
+        ref = dist2_knn(pts)
+        assert torch.allclose(got, ref, rtol=1e-5, atol=1e-9), P
+    # duplicates count with distance zero
+    pts = torch.rand(100, 3, generator=g)
+    pts[50:] = pts[:50]
+    got = distCUDA2(pts.to(DEV)).cpu()
+    assert torch.allclose(got, dist2_knn(pts), rtol=1e-5, atol=1e-9)

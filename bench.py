@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""Rasteriser fwd+bwd throughput on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+A step is one forward+backward render of BASELINE config 5 (2M Gaussians, 1920x1080, synthetic):
+preprocess, binning, blend, blend backward, per-Gaussian backward with the pose Jacobian.  With
+N > 1 (launched by torch.distributed.run, one rank per GPU) every rank renders its own keyframe of
+the mapping window against the same Gaussians and the ranks all-reduce the Gaussian gradients over
+RCCL (weak scaling: one 1080p keyframe per GPU).  Inputs are resident in HBM before the timed region.
+Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--gaussians", type=int, default=2_000_000)
+    ap.add_argument("--intrinsics", default="davis_1080p")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-steps", type=int, default=5, help="steps timed per stage with HIP events")
+    return ap.parse_args()
+
+
+def cpu_baseline():
+    """The oracle (float32 PyTorch-CPU autograd rasteriser) on a density-preserving crop of the
+    workload: same focal length and generator, 1/16 of the pixels and of the Gaussians."""
+    import torch
+
+    from monogs_amd.synthetic import make_scene, scene_settings
+    from oracle import OracleSettings, rasterize_autograd
+
+    intr = dict(fx=960.0, fy=960.0, cx=240.0, cy=135.0, W=480, H=270)
+    sc = make_scene(125_000, intr, seed=2)
+    st = scene_settings(sc, OracleSettings)
+    inp = dict(means3D=sc.means3D, opacities=sc.opacities, colors_precomp=sc.colors,
+               scales=sc.scales.repeat(1, 3), rotations=sc.rotations)
+    # the box's CPU share, not the host's core count (over-subscribing OpenMP stalls tiny ops)
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))
+    torch.set_num_threads(cores)
+    t0 = time.perf_counter()
+    rasterize_autograd(inp, st, sc.grad_color, sc.grad_depth, dtype=torch.float32)
+    dt = time.perf_counter() - t0
+    return {"value": round(intr["W"] * intr["H"] / 1e6 / dt, 5), "unit": "Mpix/s", "cores": cores, "kind": "port",
+            "sample": f"125k Gaussians, 480x270 crop of the 1080p workload (same focal length, same per-pixel "
+                      f"density), one fwd+bwd, float32, {dt:.1f} s"}
+
+
+def log(*a):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 "
+                         "--nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N ...")
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from monogs_amd.camera import se3_exp
+    from monogs_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer, collect_timing
+    from monogs_amd.synthetic import make_scene, scene_settings
+    from monogs_amd.window import GradBucket
+
+    # the map is shared by all ranks (seed 2); every rank looks at it from its own keyframe pose
+    sc = make_scene(args.gaussians, args.intrinsics, seed=2)
+    if rank:
+        d = se3_exp(torch.tensor([0.02 * rank, -0.01 * rank, 0.0, 0.0, 0.004 * rank, 0.0]))
+        T = torch.eye(4)
+        T[:3, :3], T[:3, 3] = sc.R, sc.t
+        T = d @ T
+        sc = sc._replace(R=T[:3, :3].contiguous(), t=T[:3, 3].contiguous())
+    st = scene_settings(sc, GaussianRasterizationSettings, device=dev)
+    H, W = st.image_height, st.image_width
+    leaf = lambda t: t.to(dev).clone().requires_grad_(True)  # noqa: E731
+    xyz, rgb, opac, scaling, rot = (leaf(sc.means3D), leaf(sc.colors), leaf(sc.opacities), leaf(sc.scales),
+                                    leaf(sc.rotations))
+    params = [xyz, rgb, opac, scaling, rot]
+    theta = torch.zeros(3, device=dev, requires_grad=True)
+    rho = torch.zeros(3, device=dev, requires_grad=True)
+    g_color, g_depth = sc.grad_color.to(dev), sc.grad_depth.to(dev)
+    rasterizer = GaussianRasterizer(st)
+    bucket = GradBucket(params) if world > 1 else None
+    state = {}
+
+    def step():
+        for p in params:
+            p.grad = None
+        theta.grad = rho.grad = None
+        means2D = torch.zeros_like(xyz, requires_grad=True)
+        color, radii, depth, opacity, n_touched = rasterizer(
+            means3D=xyz, means2D=means2D, opacities=opac, colors_precomp=rgb, scales=scaling.repeat(1, 3),
+            rotations=rot, theta=theta, rho=rho)
+        torch.autograd.backward([color, depth], [g_color, g_depth])
+        if bucket is not None:
+            bucket.pack()
+            bucket.all_reduce()
+            bucket.unpack()
+        state["radii"] = radii
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    log(f"scene ready: P={args.gaussians} {W}x{H}; warmup {args.warmup}")
+    for _ in range(args.warmup):
+        step()
+    fence()
+    log("warmup done; timing", args.steps, "steps")
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    log(f"timed region: {dt / args.steps * 1e3:.3f} ms/step")
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    # ---- per-kernel time, live, with HIP events on the launch stream (separate from the timed region)
+    roof = None
+    stages = {}
+    if rank == 0:
+        with collect_timing() as sink:
+            for _ in range(max(1, args.profile_steps)):
+                step()
+            torch.cuda.synchronize()
+        fw = [d for d in sink if d["kind"] == "forward"]
+        bw = [d for d in sink if d["kind"] == "backward"]
+        avg = lambda rows, k: sum(r[k] for r in rows) / max(1, len(rows))  # noqa: E731
+        for k in ("preprocess_ms", "scan_ms", "duplicate_ms", "sort_ms", "ranges_ms", "blend_fwd_ms"):
+            stages[k] = round(avg(fw, k), 4)
+        for k in ("blend_bwd_ms", "geom_bwd_ms"):
+            stages[k] = round(avg(bw, k), 4)
+        R = fw[0]["num_rendered"]
+        Pv = int((state["radii"] > 0).sum().item())
+        HW = H * W
+        # algorithmic bytes (SURVEY.md section 8d / BASELINE.md section 4)
+        b_fwd = 44 * R + 28 * HW + 4 * Pv
+        b_bwd = 44 * R + 24 * HW + 40 * Pv
+        ach = b_bwd / (stages["blend_bwd_ms"] * 1e-3) / 1e9
+        both = (b_fwd + b_bwd) / ((stages["blend_fwd_ms"] + stages["blend_bwd_ms"]) * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("blend_backward_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roof = {"bound": "hbm", "kernel": "blend_backward_kernel", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "algorithmic_bytes": b_bwd, "avg_ms": stages["blend_bwd_ms"],
+                "blend_fwd_bwd": {"achieved": round(both, 2), "frac": round(both / HBM_PEAK_GBS, 5),
+                                  "algorithmic_bytes": b_fwd + b_bwd,
+                                  "avg_ms": round(stages["blend_fwd_ms"] + stages["blend_bwd_ms"], 4)},
+                "num_rendered": R, "visible": Pv}
+
+    log("stages_ms", stages)
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        log("cpu baseline (oracle) ...")
+        cpu = cpu_baseline()
+        log("cpu baseline", cpu)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+    if rank == 0:
+        mpix = world * args.steps * H * W / 1e6 / dt
+        line = {
+            "metric": "rasteriser fwd+bwd Mpix/s @1080p", "value": round(mpix, 2), "unit": "Mpix/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"C5: {args.gaussians} Gaussians, {W}x{H}, fwd+bwd, seeded synthetic map "
+                                   f"(SURVEY.md 8d), one keyframe per GPU",
+                       "gaussians": args.gaussians, "width": W, "height": H,
+                       "parallelism": f"keyframe-per-gpu x{world}" + (" + RCCL all-reduce of 12 floats/Gaussian" if world > 1 else "")},
+            "stages_ms": stages, "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+
+
+if __name__ == "__main__":
+    main()

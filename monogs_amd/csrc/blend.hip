@@ -161,6 +161,56 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v) {
     return v;
 }
 
+// ---- packed reduction of 10 per-lane values over the 64 lanes --------------------------------
+// stage 1: v_permlane32_swap pairs (x, y): lanes 0-31 then hold x[l]+x[l+32], lanes 32-63 y[l-32]+y[l]
+// stage 2: v_permlane16_swap pairs those: each 16-lane row then holds 16 partials of ONE value
+// stage 3: row-local DPP sum -> lane 15 of each row
+__device__ __forceinline__ float swap32_add(float x, float y) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float swap16_add(float x, float y) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float row_sum_to_lane15(float v) {
+    v = dpp_add<0x111, 0xf>(v);
+    v = dpp_add<0x112, 0xf>(v);
+    v = dpp_add<0x114, 0xf>(v);
+    v = dpp_add<0x118, 0xf>(v);
+    return v;
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+// Where reduce10 leaves value k (k = gradient slot G_DX..G_DDEPTH):
+//   lane 15: a0   lane 31: a2   lane 47: a1   lane 63: a3      (register c0)
+//   lane  0: a4   lane 16: a6   lane 32: a5   lane 48: a7      (c1 rotated right by 1 inside rows)
+//   lane  1: a8   lane 33: a9                                  (c2 rotated right by 2)
+__device__ __forceinline__ int reduce10_slot(int lane) {
+    const int row = lane >> 4, pos = lane & 15;
+    if (pos == 15) return row == 0 ? 0 : row == 1 ? 2 : row == 2 ? 1 : 3;
+    if (pos == 0) return row == 0 ? 4 : row == 1 ? 6 : row == 2 ? 5 : 7;
+    if (pos == 1) return row == 0 ? 8 : row == 2 ? 9 : -1;
+    return -1;
+}
+__device__ __forceinline__ float reduce10(float a0, float a1, float a2, float a3, float a4, float a5, float a6,
+                                          float a7, float a8, float a9, int lane) {
+    const float b0 = swap32_add(a0, a1), b1 = swap32_add(a2, a3), b2 = swap32_add(a4, a5);
+    const float b3 = swap32_add(a6, a7), b4 = swap32_add(a8, a9);
+    float c0 = swap16_add(b0, b1);     // rows: a0 a2 a1 a3
+    float c1 = swap16_add(b2, b3);     // rows: a4 a6 a5 a7
+    float c2 = swap16_add(b4, b4);     // rows: a8 a8 a9 a9
+    c0 = row_sum_to_lane15(c0);
+    c1 = row_sum_to_lane15(c1);
+    c2 = row_sum_to_lane15(c2);
+    const float c1r = dpp_mov<0x121>(c1);   // row_ror:1 -> lane 0 of each row
+    const float c2r = dpp_mov<0x122>(c2);   // row_ror:2 -> lane 1 of each row
+    const int pos = lane & 15;
+    return pos == 15 ? c0 : (pos == 0 ? c1r : c2r);
+}
+
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, o, 64));
@@ -194,6 +244,7 @@ __global__ void __launch_bounds__(256) blend_backward_kernel(BlendArgs a, const 
 
     const uint32_t maxc = wave_max_u32(last);   // wave-uniform
     if (maxc == 0) return;
+    const int slot = reduce10_slot(lane);
 
     float T = T_final;
     float A = 0.f;            // sum over channels of (colour behind) * dL/dpixel, blended back to front
@@ -246,30 +297,12 @@ __global__ void __launch_bounds__(256) blend_backward_kernel(BlendArgs a, const 
                 v_b = w * g2;
                 v_z = w * gd;
             }
-            v_dx = wave_sum_to_lane63(v_dx);
-            v_dy = wave_sum_to_lane63(v_dy);
-            v_ca = wave_sum_to_lane63(v_ca);
-            v_cb = wave_sum_to_lane63(v_cb);
-            v_cc = wave_sum_to_lane63(v_cc);
-            v_op = wave_sum_to_lane63(v_op);
-            v_r = wave_sum_to_lane63(v_r);
-            v_g = wave_sum_to_lane63(v_g);
-            v_b = wave_sum_to_lane63(v_b);
-            v_z = wave_sum_to_lane63(v_z);
+            // ---- 10 wave sums in 28 VALU ops: two swap stages pack the values, then one 16-lane
+            //      row reduction per packed register (see reduce10 above); one atomic instruction
+            //      with 10 active lanes adds the whole record (a single 64-byte segment).
+            const float m = reduce10(v_dx, v_dy, v_ca, v_cb, v_cc, v_op, v_r, v_g, v_b, v_z, lane);
             const uint32_t gid = bcast(L.gid, j);
-            if (lane == 63) {
-                float* o = grad_acc + (size_t)gid * GRAD_FLOATS;
-                atomicAdd(o + G_DX, v_dx);
-                atomicAdd(o + G_DY, v_dy);
-                atomicAdd(o + G_DCA, v_ca);
-                atomicAdd(o + G_DCB, v_cb);
-                atomicAdd(o + G_DCC, v_cc);
-                atomicAdd(o + G_DOP, v_op);
-                atomicAdd(o + G_DR, v_r);
-                atomicAdd(o + G_DG, v_g);
-                atomicAdd(o + G_DB, v_b);
-                atomicAdd(o + G_DDEPTH, v_z);
-            }
+            if (slot >= 0) atomicAdd(grad_acc + (size_t)gid * GRAD_FLOATS + slot, m);
         }
     }
 }

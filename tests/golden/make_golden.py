@@ -1,0 +1,128 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory by IMPORTING the reference's own helpers
+(the ones that import on CPU here).  Run in the build container only:
+
+    python tests/golden/make_golden.py          # needs /root/reference
+
+Outputs (data only -- inputs and the reference's outputs):
+  camera_pose.npz : getProjectionMatrix / getWorld2View / CameraIntrinsics.FoV / SE3_exp / update_pose
+  sh_eval.npz     : eval_sh for degrees 0..3 on seeded inputs
+  losses.npz      : get_loss_mapping value and autograd gradients w.r.t. (render, depth) on seeded images
+"""
+import math
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+sys.path.insert(0, REF)
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+from gaussian_splatting.utils.graphics_utils import getProjectionMatrix, getWorld2View  # noqa: E402
+from gaussian_splatting.utils.sh_utils import eval_sh  # noqa: E402
+from utils.pose_utils import SE3_exp, SO3_exp, V, update_pose  # noqa: E402
+from utils.slam_utils import get_loss_mapping  # noqa: E402
+
+INTR = {
+    "fr3_office": dict(fx=535.4, fy=539.2, cx=320.1, cy=247.6, W=640, H=480),
+    "replica": dict(fx=600.0, fy=600.0, cx=599.5, cy=339.5, W=1200, H=680),
+    "davis_1080p": dict(fx=960.0, fy=960.0, cx=960.0, cy=540.0, W=1920, H=1080),
+}
+TAUS = np.array([
+    [0.0, 0.0, 0.0, 0.0, 0.0, 0.0],
+    [0.1, -0.2, 0.3, 0.05, 0.02, -0.04],
+    [-0.5, 0.25, 1.5, 0.7, -0.3, 0.2],
+    [1e-3, 2e-3, -1e-3, 1e-6, -2e-6, 3e-6],      # small-angle branch (|theta| < 1e-5)
+    [0.3, 0.1, -0.2, 1.2, 0.9, -1.4],
+], dtype=np.float32)
+
+
+def camera_pose():
+    out = {"taus": TAUS}
+    se3 = []
+    for tau in TAUS:
+        se3.append(SE3_exp(torch.tensor(tau)).numpy())
+    out["se3_exp"] = np.stack(se3)
+    out["so3_exp"] = np.stack([SO3_exp(torch.tensor(t[3:])).numpy() for t in TAUS])
+    out["V"] = np.stack([V(torch.tensor(t[3:])).numpy() for t in TAUS])
+    for name, k in INTR.items():
+        fx = torch.nn.Parameter(torch.tensor([k["fx"]]), requires_grad=False)
+        fy = torch.nn.Parameter(torch.tensor([k["fy"]]), requires_grad=False)
+        P = getProjectionMatrix(znear=0.01, zfar=100.0, fx=fx, fy=fy, cx=k["cx"], cy=k["cy"], W=k["W"], H=k["H"])
+        out[f"{name}_projection_T"] = P.transpose(0, 1).detach().numpy()
+        # /root/reference/utils/camera_utils.py:30-36
+        fovx = 2 * torch.atan(k["W"] / (2 * fx)).cpu().item()
+        fovy = 2 * torch.atan(k["H"] / (2 * fy)).cpu().item()
+        out[f"{name}_tanfov"] = np.array([math.tan(fovx * 0.5), math.tan(fovy * 0.5)], dtype=np.float64)
+        views, fulls, centers = [], [], []
+        for tau in TAUS:
+            T = SE3_exp(torch.tensor(tau))
+            w2c_T = getWorld2View(T[:3, :3], T[:3, 3]).transpose(0, 1)
+            full = (w2c_T.unsqueeze(0).bmm(P.transpose(0, 1).detach().unsqueeze(0))).squeeze(0)
+            views.append(w2c_T.numpy())
+            fulls.append(full.numpy())
+            centers.append(w2c_T.inverse()[3, :3].numpy())
+        out[f"{name}_view_T"] = np.stack(views)
+        out[f"{name}_full_T"] = np.stack(fulls)
+        out[f"{name}_campos"] = np.stack(centers)
+    # update_pose: left-multiplicative retraction and the convergence flag
+    cam = types.SimpleNamespace()
+    T0 = SE3_exp(torch.tensor(TAUS[1]))
+    cam.R, cam.T = T0[:3, :3].clone(), T0[:3, 3].clone()
+    cam.cam_trans_delta = torch.nn.Parameter(torch.tensor([0.01, -0.02, 0.005]))
+    cam.cam_rot_delta = torch.nn.Parameter(torch.tensor([0.002, 0.001, -0.003]))
+    cam.update_RT = lambda R, t: (setattr(cam, "R", R), setattr(cam, "T", t))
+    out["update_in_R"], out["update_in_T"] = T0[:3, :3].numpy(), T0[:3, 3].numpy()
+    out["update_rho"] = cam.cam_trans_delta.detach().numpy().copy()
+    out["update_theta"] = cam.cam_rot_delta.detach().numpy().copy()
+    conv = update_pose(cam)
+    out["update_out_R"], out["update_out_T"] = cam.R.detach().numpy(), cam.T.detach().numpy()
+    out["update_converged"] = np.array([bool(conv)])
+    np.savez_compressed(os.path.join(HERE, "camera_pose.npz"), **out)
+
+
+def sh_eval():
+    g = torch.Generator().manual_seed(123)
+    n = 64
+    dirs = torch.randn(n, 3, generator=g)
+    dirs = dirs / dirs.norm(dim=1, keepdim=True)
+    sh = torch.randn(n, 3, 16, generator=g)          # [..., C, coeffs] as eval_sh expects
+    out = {"dirs": dirs.numpy(), "sh": sh.numpy()}
+    for deg in range(4):
+        out[f"deg{deg}"] = eval_sh(deg, sh, dirs).numpy()
+    np.savez_compressed(os.path.join(HERE, "sh_eval.npz"), **out)
+
+
+def losses():
+    g = torch.Generator().manual_seed(7)
+    H, W = 24, 32
+    vp = types.SimpleNamespace()
+    vp.rgb = torch.rand(3, H, W, generator=g)
+    vp.depth = torch.rand(H, W, generator=g) * 3.0
+    vp.depth[torch.rand(H, W, generator=g) < 0.2] = 0.0             # invalid depth pixels
+    vp.mask = torch.rand(H, W, generator=g) > 0.1
+    vp.exposure_a = torch.tensor([0.05])
+    vp.exposure_b = torch.tensor([-0.02])
+    render = torch.rand(3, H, W, generator=g).requires_grad_(True)
+    depth = (torch.rand(1, H, W, generator=g) * 3.0).requires_grad_(True)
+    out = {"gt_rgb": vp.rgb.numpy(), "gt_depth": vp.depth.numpy(), "gt_mask": vp.mask.numpy(),
+           "exposure": np.array([0.05, -0.02], dtype=np.float32),
+           "render": render.detach().numpy(), "depth": depth.detach().numpy()}
+    for init in (False, True):
+        loss = get_loss_mapping(render, depth, vp, init=init)
+        gr, gd = torch.autograd.grad(loss, [render, depth])
+        tag = "init" if init else "map"
+        out[f"loss_{tag}"] = np.array([loss.item()], dtype=np.float64)
+        out[f"grad_render_{tag}"] = gr.numpy()
+        out[f"grad_depth_{tag}"] = gd.numpy()
+    np.savez_compressed(os.path.join(HERE, "losses.npz"), **out)
+
+
+if __name__ == "__main__":
+    camera_pose()
+    sh_eval()
+    losses()
+    print("golden fixtures written to", HERE)

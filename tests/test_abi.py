@@ -1,0 +1,68 @@
+"""The C-ABI library builds for gfx950 without a GPU, loads, and exports every symbol that
+include/monogs_raster.h declares (no compute calls here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "monogs_raster.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mgs_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_the_expected_entry_points():
+    syms = _declared_symbols()
+    for s in ("mgs_forward_preprocess", "mgs_forward_render", "mgs_backward", "mgs_mark_visible", "mgs_dist2_knn",
+              "mgs_geometry_bytes", "mgs_image_bytes", "mgs_binning_bytes", "mgs_backward_bytes",
+              "mgs_knn_scratch_bytes", "mgs_abi_version", "mgs_last_error"):
+        assert s in syms
+
+
+def test_library_exports_every_declared_symbol(native_lib):
+    from monogs_amd import _lib
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for s in _declared_symbols():
+        assert hasattr(raw, s), f"{s} declared in the header but not exported"
+    assert set(_lib.SIGNATURES) == set(_declared_symbols())
+    assert native_lib.mgs_abi_version() == _lib.ABI_VERSION
+
+
+def test_scratch_size_functions_are_pure(native_lib):
+    assert native_lib.mgs_geometry_bytes(0) >= 256
+    a, b = native_lib.mgs_geometry_bytes(1000), native_lib.mgs_geometry_bytes(2000)
+    assert b > a >= 1000 * 64
+    assert native_lib.mgs_image_bytes(640, 480) >= 640 * 480 * 8 + 1200 * 8
+    assert native_lib.mgs_backward_bytes(1000) >= 1000 * 64
+    assert native_lib.mgs_knn_scratch_bytes(10) > 0
+
+
+def test_struct_layout_matches_header():
+    from monogs_amd import _lib
+    assert ctypes.sizeof(_lib.MgsCamera) == 8 * 4 + 5 * 8
+    assert ctypes.sizeof(_lib.MgsTiming) == 8 * 4
+
+
+def test_code_object_targets_gfx950(native_lib):
+    from monogs_amd import _lib
+    blob = open(_lib.LIB_PATH, "rb").read()
+    targets = set(re.findall(rb"amdgcn-amd-amdhsa--(gfx[0-9a-f]+)", blob))
+    assert targets == {b"gfx950"}, targets
+
+
+def test_product_path_has_no_cpu_fallback():
+    """Nothing under monogs_amd/ may import the oracle, and CPU tensors are rejected."""
+    import torch
+
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "monogs_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+    from monogs_amd.knn import distCUDA2
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        distCUDA2(torch.zeros(10, 3))

@@ -109,14 +109,14 @@ __global__ void __launch_bounds__(256) duplicate_kernel(int P, const float* __re
     if (tiles_touched[idx] == 0) return;          // culled: its record was never written
     uint32_t off = idx == 0 ? 0u : offsets[idx - 1];
     const float4 r0 = reinterpret_cast<const float4*>(rec + (size_t)idx * REC_FLOATS)[0];
-    const float radius = rec[(size_t)idx * REC_FLOATS + 15];
+    const float radius = rec[(size_t)idx * REC_FLOATS + R_RADIUS];
     const float px = r0.x, py = r0.y;
     // same expressions as preprocess (integer truncation of a float quotient)
     const int x0 = min(gx, max(0, (int)((px - radius) / (float)TILE)));
     const int y0 = min(gy, max(0, (int)((py - radius) / (float)TILE)));
     const int x1 = min(gx, max(0, (int)(((px + radius) + (float)(TILE - 1)) / (float)TILE)));
     const int y1 = min(gy, max(0, (int)(((py + radius) + (float)(TILE - 1)) / (float)TILE)));
-    const uint64_t depth_bits = (uint64_t)__float_as_uint(r0.z);
+    const uint64_t depth_bits = (uint64_t)__float_as_uint(rec[(size_t)idx * REC_FLOATS + R_DEPTH]);
     for (int y = y0; y < y1; ++y)
         for (int x = x0; x < x1; ++x) {
             keys[off] = ((uint64_t)(uint32_t)(y * gx + x) << 32) | depth_bits;

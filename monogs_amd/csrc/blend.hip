@@ -8,11 +8,13 @@
 // gfx950 mapping.  A 16x16 tile is one 256-thread workgroup, but its four wavefronts never
 // synchronise: wave w owns the 8x8 pixel quadrant (w&1, w>>1), one pixel per lane, and walks the
 // tile's instance list on its own, 64 instances per step:
-//   1. lane l loads instance l of the step: the Gaussian index (coalesced) and its 64-byte record;
-//   2. lane l tests the record's alpha>=1/255 bounding box against the wave's quadrant;
+//   1. lane l loads instance l of the step: the Gaussian index (coalesced) and float4 #0 of its
+//      64-byte record, {px, py, ex, ey};
+//   2. lane l tests the alpha >= 1/255 bounding box (px +- ex, py +- ey) against the wave's quadrant;
 //      __ballot compacts the survivors into a 64-bit mask held in scalar registers;
-//   3. the wave pops survivors off the mask; v_readlane broadcasts the survivor's record into
-//      SGPRs, and all 64 lanes (pixels) evaluate it with scalar operands.
+//   3. the wave pops survivors off the mask; ONE v_readlane fetches the survivor's Gaussian index and
+//      the rest of its record arrives through the scalar cache (s_load_dwordx8 + s_load_dwordx4) --
+//      all 64 lanes (pixels) then evaluate it with SGPR operands.
 // No LDS, no barriers; a quadrant whose pixels are all saturated retires early.
 // Skipping an instance for a whole quadrant never changes a pixel: every skipped pair has
 // alpha < 1/255 and the per-pixel rule would have skipped it too.
@@ -20,43 +22,40 @@
 
 namespace mgs {
 
-__device__ __forceinline__ float bcast(float v, int lane) {
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
-}
 __device__ __forceinline__ uint32_t bcast(uint32_t v, int lane) {
     return (uint32_t)__builtin_amdgcn_readlane((int)v, lane);
 }
 
 struct BlendArgs {
-    const float* __restrict__ rec;
+    const float4* __restrict__ rec;            // [P][4]
     const uint32_t* __restrict__ point_list;
     const uint2* __restrict__ ranges;
     const float* __restrict__ bg;
     int W, H, gx;
 };
 
-// record of the instance held by a lane + quadrant box test
-struct LaneRec {
-    float4 r0, r1, r2;
-    uint32_t gid;
-};
-
+// lane-held instance: index + cull box test against the wave's quadrant
 __device__ __forceinline__ bool load_and_test(const BlendArgs& a, uint32_t i, uint32_t end, float qx0, float qy0,
-                                              LaneRec& L) {
-    const bool valid = i < end;
-    L.gid = 0;
+                                              uint32_t& gid) {
+    gid = 0;
     bool hit = false;
-    if (valid) {
-        L.gid = a.point_list[i];
-        const float4* r = reinterpret_cast<const float4*>(a.rec + (size_t)L.gid * REC_FLOATS);
-        L.r0 = r[0];
-        L.r1 = r[1];
-        L.r2 = r[2];
-        const float ex = L.r1.w, ey = L.r2.w;
-        hit = (L.r0.x + ex >= qx0) && (L.r0.x - ex <= qx0 + (float)(SUB - 1)) && (L.r0.y + ey >= qy0) &&
-              (L.r0.y - ey <= qy0 + (float)(SUB - 1));
+    if (i < end) {
+        gid = a.point_list[i];
+        const float4 c = a.rec[(size_t)gid * 4];           // {px, py, ex, ey}
+        hit = (c.x + c.z >= qx0) && (c.x - c.z <= qx0 + (float)(SUB - 1)) && (c.y + c.w >= qy0) &&
+              (c.y - c.w <= qy0 + (float)(SUB - 1));
     }
     return hit;
+}
+
+// the survivor's record through the scalar cache (wave-uniform address -> s_load)
+struct Rec {
+    float px, py, ca, cb, cc, op, r, g, b, z;
+};
+__device__ __forceinline__ Rec fetch(const BlendArgs& a, uint32_t gid_uniform) {
+    const float4* p = a.rec + (size_t)gid_uniform * 4;
+    const float4 r0 = p[0], r1 = p[1], r2 = p[2];
+    return Rec{r0.x, r0.y, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
 }
 
 __global__ void __launch_bounds__(256) blend_forward_kernel(BlendArgs a, float* __restrict__ out_color,
@@ -81,35 +80,31 @@ __global__ void __launch_bounds__(256) blend_forward_kernel(BlendArgs a, float* 
 
     for (uint32_t base = range.x; base < range.y; base += WAVE) {
         if (__ballot(!done) == 0ull) break;
-        LaneRec L;
-        const bool hit = load_and_test(a, base + lane, range.y, qx0, qy0, L);
+        uint32_t gid_l;
+        const bool hit = load_and_test(a, base + lane, range.y, qx0, qy0, gid_l);
         unsigned long long mask = __ballot(hit);
         while (mask) {
             const int j = __builtin_ctzll(mask);
             mask &= mask - 1;
-            const float gxp = bcast(L.r0.x, j), gyp = bcast(L.r0.y, j), gz = bcast(L.r0.z, j), op = bcast(L.r0.w, j);
-            const float ca = bcast(L.r1.x, j), cb = bcast(L.r1.y, j), cc = bcast(L.r1.z, j);
-            const float cr = bcast(L.r2.x, j), cg = bcast(L.r2.y, j), cbl = bcast(L.r2.z, j);
-            const float dx = gxp - pxf, dy = gyp - pyf;
-            const float power = -0.5f * (ca * dx * dx + cc * dy * dy) - cb * dx * dy;
-            const float alpha = fminf(0.99f, op * __expf(power));
+            const uint32_t gid = bcast(gid_l, j);
+            const Rec g = fetch(a, gid);
+            const float dx = g.px - pxf, dy = g.py - pyf;
+            const float power = -0.5f * (g.ca * dx * dx + g.cc * dy * dy) - g.cb * dx * dy;
+            const float alpha = fminf(0.99f, g.op * __expf(power));
             const bool act = !done && !(power > 0.f) && !(alpha < 1.0f / 255.0f);
             const float test_T = T * (1.f - alpha);
             const bool stop = act && (test_T < 0.0001f);
             done = done || stop;
             const bool contrib = act && !stop;
-            if (contrib) {
-                const float w = alpha * T;
-                C0 += cr * w;
-                C1 += cg * w;
-                C2 += cbl * w;
-                D += gz * w;
-                T = test_T;
-                last = (base - range.x) + (uint32_t)j + 1u;
-            }
+            const float w = contrib ? alpha * T : 0.f;
+            C0 += g.r * w;
+            C1 += g.g * w;
+            C2 += g.b * w;
+            D += g.z * w;
+            T = contrib ? test_T : T;
+            last = contrib ? (base - range.x) + (uint32_t)j + 1u : last;
             const unsigned long long touched = __ballot(contrib && test_T > 0.5f);
             if (touched) {
-                const uint32_t gid = bcast(L.gid, j);
                 if (lane == 0) atomicAdd(n_touched + gid, (int)__popcll(touched));
             }
             if (__ballot(!done) == 0ull) break;
@@ -127,12 +122,23 @@ __global__ void __launch_bounds__(256) blend_forward_kernel(BlendArgs a, float* 
     }
 }
 
+static BlendArgs make_args(const mgs_camera& cam, const GeometryState& g, const BinningState& b,
+                           const ImageState& img) {
+    BlendArgs a;
+    a.rec = reinterpret_cast<const float4*>(g.rec);
+    a.point_list = b.vals_sorted;
+    a.ranges = img.ranges;
+    a.bg = cam.bg;
+    a.W = cam.image_width;
+    a.H = cam.image_height;
+    a.gx = tiles_x(a.W);
+    return a;
+}
+
 int launch_blend_forward(const mgs_camera& cam, const GeometryState& g, const BinningState& b,
                          const ImageState& img, float* out_color, float* out_depth, float* out_opacity,
                          int32_t* n_touched, hipStream_t s) {
-    BlendArgs a;
-    a.rec = g.rec; a.point_list = b.vals_sorted; a.ranges = img.ranges; a.bg = cam.bg;
-    a.W = cam.image_width; a.H = cam.image_height; a.gx = tiles_x(a.W);
+    const BlendArgs a = make_args(cam, g, b, img);
     const int ntiles = a.gx * tiles_y(a.H);
     if (ntiles == 0) return 0;
     hipLaunchKernelGGL(blend_forward_kernel, dim3(ntiles), dim3(256), 0, s, a, out_color, out_depth, out_opacity,
@@ -145,20 +151,10 @@ int launch_blend_forward(const mgs_camera& cam, const GeometryState& g, const Bi
 // backward: the same walk, back to front, from the pixel's last contributor
 // =================================================================================================
 
-// sum over the 64 lanes, result valid in lane 63 (4 row-local DPP steps + 2 row broadcasts)
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp_add(float v) {
     const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true);
     return v + __int_as_float(moved);
-}
-__device__ __forceinline__ float wave_sum_to_lane63(float v) {
-    v = dpp_add<0x111, 0xf>(v);   // row_shr:1
-    v = dpp_add<0x112, 0xf>(v);   // row_shr:2
-    v = dpp_add<0x114, 0xf>(v);   // row_shr:4
-    v = dpp_add<0x118, 0xf>(v);   // row_shr:8   -> lane 15 of each row holds the row sum
-    v = dpp_add<0x142, 0xa>(v);   // row_bcast:15 into rows 1,3
-    v = dpp_add<0x143, 0xc>(v);   // row_bcast:31 into rows 2,3 -> lane 63 holds the wave sum
-    return v;
 }
 
 // ---- packed reduction of 10 per-lane values over the 64 lanes --------------------------------
@@ -174,17 +170,17 @@ __device__ __forceinline__ float swap16_add(float x, float y) {
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 __device__ __forceinline__ float row_sum_to_lane15(float v) {
-    v = dpp_add<0x111, 0xf>(v);
-    v = dpp_add<0x112, 0xf>(v);
-    v = dpp_add<0x114, 0xf>(v);
-    v = dpp_add<0x118, 0xf>(v);
+    v = dpp_add<0x111, 0xf>(v);   // row_shr:1
+    v = dpp_add<0x112, 0xf>(v);   // row_shr:2
+    v = dpp_add<0x114, 0xf>(v);   // row_shr:4
+    v = dpp_add<0x118, 0xf>(v);   // row_shr:8
     return v;
 }
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
 }
-// Where reduce10 leaves value k (k = gradient slot G_DX..G_DDEPTH):
+// Where reduce10 leaves value k (k = gradient slot G_SX..G_DDEPTH):
 //   lane 15: a0   lane 31: a2   lane 47: a1   lane 63: a3      (register c0)
 //   lane  0: a4   lane 16: a6   lane 32: a5   lane 48: a7      (c1 rotated right by 1 inside rows)
 //   lane  1: a8   lane 33: a9                                  (c2 rotated right by 2)
@@ -240,7 +236,7 @@ __global__ void __launch_bounds__(256) blend_backward_kernel(BlendArgs a, const 
     const float g1 = inside ? dL_dcolor[HW + pix] : 0.f;
     const float g2 = inside ? dL_dcolor[2 * HW + pix] : 0.f;
     const float gd = inside ? dL_ddepth[pix] : 0.f;
-    const float bg_dot = a.bg[0] * g0 + a.bg[1] * g1 + a.bg[2] * g2;
+    const float bgT = -T_final * (a.bg[0] * g0 + a.bg[1] * g1 + a.bg[2] * g2);   // background term, per pixel
 
     const uint32_t maxc = wave_max_u32(last);   // wave-uniform
     if (maxc == 0) return;
@@ -253,55 +249,39 @@ __global__ void __launch_bounds__(256) blend_backward_kernel(BlendArgs a, const 
 
     for (int b = (int)((maxc - 1) / WAVE); b >= 0; --b) {
         const uint32_t base = range.x + (uint32_t)b * WAVE;
-        LaneRec L;
-        const bool hit = load_and_test(a, base + lane, end, qx0, qy0, L);
+        uint32_t gid_l;
+        const bool hit = load_and_test(a, base + lane, end, qx0, qy0, gid_l);
         unsigned long long mask = __ballot(hit);
         while (mask) {
             const int j = 63 - __builtin_clzll(mask);
             mask &= ~(1ull << j);
             const uint32_t k = (uint32_t)b * WAVE + (uint32_t)j + 1u;     // 1-based position in the tile list
-            const float gxp = bcast(L.r0.x, j), gyp = bcast(L.r0.y, j), gz = bcast(L.r0.z, j), op = bcast(L.r0.w, j);
-            const float ca = bcast(L.r1.x, j), cb = bcast(L.r1.y, j), cc = bcast(L.r1.z, j);
-            const float cr = bcast(L.r2.x, j), cg = bcast(L.r2.y, j), cbl = bcast(L.r2.z, j);
-            const float dx = gxp - pxf, dy = gyp - pyf;
-            const float power = -0.5f * (ca * dx * dx + cc * dy * dy) - cb * dx * dy;
+            const uint32_t gid = bcast(gid_l, j);
+            const Rec g = fetch(a, gid);
+            const float dx = g.px - pxf, dy = g.py - pyf;
+            const float power = -0.5f * (g.ca * dx * dx + g.cc * dy * dy) - g.cb * dx * dy;
             const float G = __expf(power);
-            const float alpha = fminf(0.99f, op * G);
+            const float alpha = fminf(0.99f, g.op * G);
             const bool act = (k <= last) && !(power > 0.f) && !(alpha < 1.0f / 255.0f);
             if (__ballot(act) == 0ull) continue;
 
-            float v_dx = 0.f, v_dy = 0.f, v_ca = 0.f, v_cb = 0.f, v_cc = 0.f, v_op = 0.f;
-            float v_r = 0.f, v_g = 0.f, v_b = 0.f, v_z = 0.f;
-            if (act) {
-                const float inv = 1.f / (1.f - alpha);
-                T = T * inv;
-                const float w = alpha * T;
-                const float q = (cr * g0 + cg * g1) + (cbl * g2 + gz * gd);
-                A = last_alpha * last_q + (1.f - last_alpha) * A;
-                last_q = q;
-                last_alpha = alpha;
-                float dL_dalpha = (q - A) * T;
-                dL_dalpha += (-T_final * inv) * bg_dot;
-                const float dL_dG = op * dL_dalpha;
-                const float gdx = G * dx, gdy = G * dy;
-                const float dG_ddelx = -gdx * ca - gdy * cb;
-                const float dG_ddely = -gdy * cc - gdx * cb;
-                v_dx = dL_dG * dG_ddelx;
-                v_dy = dL_dG * dG_ddely;
-                v_ca = -0.5f * gdx * dx * dL_dG;
-                v_cb = -gdx * dy * dL_dG;
-                v_cc = -0.5f * gdy * dy * dL_dG;
-                v_op = G * dL_dalpha;
-                v_r = w * g0;
-                v_g = w * g1;
-                v_b = w * g2;
-                v_z = w * gd;
-            }
-            // ---- 10 wave sums in 28 VALU ops: two swap stages pack the values, then one 16-lane
-            //      row reduction per packed register (see reduce10 above); one atomic instruction
-            //      with 10 active lanes adds the whole record (a single 64-byte segment).
-            const float m = reduce10(v_dx, v_dy, v_ca, v_cb, v_cc, v_op, v_r, v_g, v_b, v_z, lane);
-            const uint32_t gid = bcast(L.gid, j);
+            // Everything below runs for all 64 lanes; an inactive lane contributes exact zeros
+            // (w = 0, h = 0) and keeps its state.
+            const float inv = __builtin_amdgcn_rcpf(1.f - alpha);   // v_rcp_f32, not the IEEE divide sequence
+            const float Tn = T * inv;
+            const float q = (g.r * g0 + g.g * g1) + (g.b * g2 + g.z * gd);
+            const float An = A + last_alpha * (last_q - A);          // = last_alpha*last_q + (1-last_alpha)*A
+            const float dL_dalpha = (q - An) * Tn + bgT * inv;
+            const float w = act ? alpha * Tn : 0.f;
+            const float h = act ? G * dL_dalpha : 0.f;               // g.op and the conic are applied per Gaussian later
+            T = act ? Tn : T;
+            A = act ? An : A;
+            last_q = act ? q : last_q;
+            last_alpha = act ? alpha : last_alpha;
+            const float hx = h * dx, hy = h * dy;
+            // ---- 10 wave sums in 28 VALU ops, then ONE atomic instruction with 10 active lanes
+            //      covering the Gaussian's 64-byte gradient line
+            const float m = reduce10(hx, hy, hx * dx, hx * dy, hy * dy, h, w * g0, w * g1, w * g2, w * gd, lane);
             if (slot >= 0) atomicAdd(grad_acc + (size_t)gid * GRAD_FLOATS + slot, m);
         }
     }
@@ -310,9 +290,7 @@ __global__ void __launch_bounds__(256) blend_backward_kernel(BlendArgs a, const 
 int launch_blend_backward(const mgs_camera& cam, const GeometryState& g, const BinningState& b,
                           const ImageState& img, const float* dL_dcolor, const float* dL_ddepth, float* grad_acc,
                           hipStream_t s) {
-    BlendArgs a;
-    a.rec = g.rec; a.point_list = b.vals_sorted; a.ranges = img.ranges; a.bg = cam.bg;
-    a.W = cam.image_width; a.H = cam.image_height; a.gx = tiles_x(a.W);
+    const BlendArgs a = make_args(cam, g, b, img);
     const int ntiles = a.gx * tiles_y(a.H);
     if (ntiles == 0) return 0;
     hipLaunchKernelGGL(blend_backward_kernel, dim3(ntiles), dim3(256), 0, s, a, img.final_T, img.n_contrib, dL_dcolor,

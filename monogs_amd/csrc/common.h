@@ -15,16 +15,24 @@ constexpr int SUB = 8;                  // one wave blends an 8x8 quadrant of a 
 constexpr int REC_FLOATS = 16;          // per-Gaussian blend record: one 64-byte line
 constexpr int GRAD_FLOATS = 16;         // per-Gaussian gradient accumulator: one 64-byte line
 
-// blend record slots (float index inside the 64-byte record written by preprocess)
+// blend record slots (float index inside the 64-byte record written by preprocess):
+//   float4 #0 {px, py, ex, ey}   what a lane needs for the quadrant cull test
+//   float4 #1 {conic a, b, c, opacity}   } fetched with scalar loads for a surviving instance
+//   float4 #2 {r, g, b, depth}           }
+//   float4 #3 {cov_xx, cov_xy, cov_yy, radius}   backward / duplicate only
 enum : int {
-    R_X = 0, R_Y = 1, R_DEPTH = 2, R_OPAC = 3,
-    R_CA = 4, R_CB = 5, R_CC = 6, R_EX = 7,
-    R_R = 8, R_G = 9, R_B = 10, R_EY = 11,
-    R_COVXX = 12, R_COVXY = 13, R_COVYY = 14, R_SPARE = 15
+    R_X = 0, R_Y = 1, R_EX = 2, R_EY = 3,
+    R_CA = 4, R_CB = 5, R_CC = 6, R_OPAC = 7,
+    R_R = 8, R_G = 9, R_B = 10, R_DEPTH = 11,
+    R_COVXX = 12, R_COVXY = 13, R_COVYY = 14, R_RADIUS = 15
 };
-// gradient accumulator slots (written with float atomics by the blend backward)
+// gradient accumulator slots (float atomics by the blend backward).  With h = G * dL/dalpha summed
+// over the pixels of every tile the Gaussian touches, the blend backward stores the RAW moments
+//   S_X = sum h dx, S_Y = sum h dy, S_XX = sum h dx^2, S_XY = sum h dx dy, S_YY = sum h dy^2, S_H = sum h
+// (d = mean2D - pixel); the per-Gaussian constants (conic, opacity, -1/2) are applied once per
+// Gaussian in geom_backward instead of once per (pixel, instance) pair -- the map is linear.
 enum : int {
-    G_DX = 0, G_DY = 1, G_DCA = 2, G_DCB = 3, G_DCC = 4, G_DOP = 5,
+    G_SX = 0, G_SY = 1, G_SXX = 2, G_SXY = 3, G_SYY = 4, G_SH = 5,
     G_DR = 6, G_DG = 7, G_DB = 8, G_DDEPTH = 9
 };
 

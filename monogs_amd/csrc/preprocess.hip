@@ -227,9 +227,9 @@ __global__ void __launch_bounds__(256) preprocess_forward_kernel(PreArgs a) {
     }
 
     float4* rec = reinterpret_cast<float4*>(a.rec + (size_t)idx * REC_FLOATS);
-    rec[0] = make_float4(px, py, pv[2], opac);
-    rec[1] = make_float4(ca, cb, cc, ex);
-    rec[2] = make_float4(rgb[0], rgb[1], rgb[2], ey);
+    rec[0] = make_float4(px, py, ex, ey);
+    rec[1] = make_float4(ca, cb, cc, opac);
+    rec[2] = make_float4(rgb[0], rgb[1], rgb[2], pv[2]);
     rec[3] = make_float4(p.cxx, p.cxy, p.cyy, radius);
     a.radii[idx] = (int)radius;
     a.tiles_touched[idx] = (uint32_t)ntile;
@@ -318,8 +318,9 @@ __global__ void __launch_bounds__(256) geom_backward_kernel(BwdArgs a) {
         // ---- conic -> 2-D covariance.  Q = C^-1;  dL/dC = -Q G Q with G the symmetric matrix
         //      [[gA, gB/2],[gB/2, gC]] (gB is the derivative w.r.t. the scalar b of power = -a dx^2/2 - c dy^2/2 - b dx dy)
         const float4 r1 = reinterpret_cast<const float4*>(a.rec + (size_t)idx * REC_FLOATS)[1];
-        const float qa = r1.x, qb = r1.y, qc = r1.z;
-        const float gA = ga[G_DCA], gBh = 0.5f * ga[G_DCB], gC = ga[G_DCC];
+        const float qa = r1.x, qb = r1.y, qc = r1.z, opq = r1.w;
+        // raw moments -> gradients w.r.t. the conic entries and the pixel-space mean (see common.h)
+        const float gA = -0.5f * opq * ga[G_SXX], gBh = 0.5f * (-opq * ga[G_SXY]), gC = -0.5f * opq * ga[G_SYY];
         // N = G Q
         const float n00 = gA * qa + gBh * qb, n01 = gA * qb + gBh * qc;
         const float n10 = gBh * qa + gC * qb, n11 = gBh * qb + gC * qc;
@@ -367,7 +368,8 @@ __global__ void __launch_bounds__(256) geom_backward_kernel(BwdArgs a) {
                  2.f * c.focal_y * p.ty * itz3 * dJ12;
 
         // ---- pixel mean:  pix = ((ndc + 1) S - 1)/2,  ndc = ph.xy / (ph.w + 1e-7),  ph = P_raw [p_c; 1]
-        const float gpx = ga[G_DX], gpy = ga[G_DY];
+        const float gpx = -opq * (qa * ga[G_SX] + qb * ga[G_SY]);
+        const float gpy = -opq * (qc * ga[G_SY] + qb * ga[G_SX]);
         const float gnx = gpx * 0.5f * (float)a.W, gny = gpy * 0.5f * (float)a.H;
         if (a.g.dL_dmeans2D) { a.g.dL_dmeans2D[3 * idx] = gnx; a.g.dL_dmeans2D[3 * idx + 1] = gny; }
         float ph[4];
@@ -452,7 +454,7 @@ __global__ void __launch_bounds__(256) geom_backward_kernel(BwdArgs a) {
             for (int i = 0; i < 3; ++i)
                 tau[i] += (c.V[i] * gmean_w[0] + c.V[4 + i] * gmean_w[1]) + c.V[8 + i] * gmean_w[2];
         }
-        if (a.g.dL_dopacity) a.g.dL_dopacity[idx] = ga[G_DOP];
+        if (a.g.dL_dopacity) a.g.dL_dopacity[idx] = ga[G_SH];
 
         // ---- world-space mean:  p_c = Rv p + t
         if (a.g.dL_dmeans3D) {

@@ -34,20 +34,6 @@ struct BlendArgs {
     int W, H, gx;
 };
 
-// lane-held instance: index + cull box test against the wave's quadrant
-__device__ __forceinline__ bool load_and_test(const BlendArgs& a, uint32_t i, uint32_t end, float qx0, float qy0,
-                                              uint32_t& gid) {
-    gid = 0;
-    bool hit = false;
-    if (i < end) {
-        gid = a.point_list[i];
-        const float4 c = a.rec[(size_t)gid * 4];           // {px, py, ex, ey}
-        hit = (c.x + c.z >= qx0) && (c.x - c.z <= qx0 + (float)(SUB - 1)) && (c.y + c.w >= qy0) &&
-              (c.y - c.w <= qy0 + (float)(SUB - 1));
-    }
-    return hit;
-}
-
 // the survivor's record through the scalar cache (wave-uniform address -> s_load)
 struct Rec {
     float px, py, ca, cb, cc, op, r, g, b, z;
@@ -74,15 +60,31 @@ __global__ void __launch_bounds__(256) blend_forward_kernel(BlendArgs a, float* 
     const float qx0 = (float)qx0i, qy0 = (float)qy0i;
     const uint2 range = a.ranges[tile];
 
-    float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f;
+    // T is the running transmittance and doubles as the "still blending" flag: a pixel that
+    // terminates (or lies outside the image) gets T = 0, after which every later instance fails the
+    // T(1-alpha) >= 1e-4 test by itself and contributes w = alpha*T = 0.  Tf keeps the value to store.
+    float T = inside ? 1.f : 0.f, Tf = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f;
     uint32_t last = 0;
-    bool done = !inside;
 
+    uint32_t gid_n = 0;
+    float4 box_n = make_float4(0.f, 0.f, -1.f, -1.f);
+    auto prefetch = [&](uint32_t i) {               // next step's index + cull box, issued one step ahead
+        gid_n = 0;
+        box_n = make_float4(0.f, 0.f, -1.f, -1.f);
+        if (i < range.y) {
+            gid_n = a.point_list[i];
+            box_n = a.rec[(size_t)gid_n * 4];
+        }
+    };
+    if (range.x < range.y) prefetch(range.x + lane);
     for (uint32_t base = range.x; base < range.y; base += WAVE) {
-        if (__ballot(!done) == 0ull) break;
-        uint32_t gid_l;
-        const bool hit = load_and_test(a, base + lane, range.y, qx0, qy0, gid_l);
+        const uint32_t gid_l = gid_n;
+        const float4 c = box_n;
+        prefetch(base + WAVE + lane);
+        const bool hit = (c.x + c.z >= qx0) && (c.x - c.z <= qx0 + (float)(SUB - 1)) && (c.y + c.w >= qy0) &&
+                         (c.y - c.w <= qy0 + (float)(SUB - 1));
         unsigned long long mask = __ballot(hit);
+        bool all_done = false;
         while (mask) {
             const int j = __builtin_ctzll(mask);
             mask &= mask - 1;
@@ -91,25 +93,29 @@ __global__ void __launch_bounds__(256) blend_forward_kernel(BlendArgs a, float* 
             const float dx = g.px - pxf, dy = g.py - pyf;
             const float power = -0.5f * (g.ca * dx * dx + g.cc * dy * dy) - g.cb * dx * dy;
             const float alpha = fminf(0.99f, g.op * __expf(power));
-            const bool act = !done && !(power > 0.f) && !(alpha < 1.0f / 255.0f);
+            const bool act = !(power > 0.f) && !(alpha < 1.0f / 255.0f);
             const float test_T = T * (1.f - alpha);
             const bool stop = act && (test_T < 0.0001f);
-            done = done || stop;
             const bool contrib = act && !stop;
             const float w = contrib ? alpha * T : 0.f;
             C0 += g.r * w;
             C1 += g.g * w;
             C2 += g.b * w;
             D += g.z * w;
-            T = contrib ? test_T : T;
+            Tf = contrib ? test_T : Tf;
+            T = stop ? 0.f : (contrib ? test_T : T);
             last = contrib ? (base - range.x) + (uint32_t)j + 1u : last;
             const unsigned long long touched = __ballot(contrib && test_T > 0.5f);
             if (touched) {
                 if (lane == 0) atomicAdd(n_touched + gid, (int)__popcll(touched));
             }
-            if (__ballot(!done) == 0ull) break;
+            if (__ballot(stop)) {                      // rare: re-check whether the whole quadrant is finished
+                if (__ballot(T != 0.f) == 0ull) { all_done = true; break; }
+            }
         }
+        if (all_done) break;
     }
+    T = Tf;
     if (inside) {
         const size_t pix = (size_t)pyi * a.W + pxi, HW = (size_t)a.H * a.W;
         final_T[pix] = T;
@@ -247,10 +253,24 @@ __global__ void __launch_bounds__(256) blend_backward_kernel(BlendArgs a, const 
     float last_alpha = 0.f, last_q = 0.f;
     const uint32_t end = range.x + maxc;
 
+    uint32_t gid_n = 0;
+    float4 box_n = make_float4(0.f, 0.f, -1.f, -1.f);
+    auto prefetch = [&](int b) {                    // next step's index + cull box, issued one step ahead
+        gid_n = 0;
+        box_n = make_float4(0.f, 0.f, -1.f, -1.f);
+        const uint32_t i = range.x + (uint32_t)b * WAVE + lane;
+        if (b >= 0 && i < end) {
+            gid_n = a.point_list[i];
+            box_n = a.rec[(size_t)gid_n * 4];
+        }
+    };
+    prefetch((int)((maxc - 1) / WAVE));
     for (int b = (int)((maxc - 1) / WAVE); b >= 0; --b) {
-        const uint32_t base = range.x + (uint32_t)b * WAVE;
-        uint32_t gid_l;
-        const bool hit = load_and_test(a, base + lane, end, qx0, qy0, gid_l);
+        const uint32_t gid_l = gid_n;
+        const float4 c = box_n;
+        prefetch(b - 1);
+        const bool hit = (c.x + c.z >= qx0) && (c.x - c.z <= qx0 + (float)(SUB - 1)) && (c.y + c.w >= qy0) &&
+                         (c.y - c.w <= qy0 + (float)(SUB - 1));
         unsigned long long mask = __ballot(hit);
         while (mask) {
             const int j = 63 - __builtin_clzll(mask);

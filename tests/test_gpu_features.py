@@ -1,0 +1,208 @@
+"""HIP path vs oracle for the rest of the API surface and the edge cases (pytest -m gpu)."""
+import types
+
+import pytest
+import torch
+
+from monogs_amd import camera as cam
+from monogs_amd.synthetic import make_scene, scene_settings
+from oracle import OracleSettings, gs_oracle, rasterize, rasterize_autograd
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _hip_st(sc, **kw):
+    from monogs_amd.rasterizer import GaussianRasterizationSettings
+    return scene_settings(sc, GaussianRasterizationSettings, device=DEV, **kw)
+
+
+def _run(sc, inp, st, ost, rtol=1e-3):
+    from monogs_amd.rasterizer import GaussianRasterizer
+    leaves = {k: v.to(DEV).clone().requires_grad_(True) for k, v in inp.items()}
+    m2d = torch.zeros_like(leaves["means3D"], requires_grad=True)
+    theta = torch.zeros(3, device=DEV, requires_grad=True)
+    rho = torch.zeros(3, device=DEV, requires_grad=True)
+    out = GaussianRasterizer(st)(means3D=leaves["means3D"], means2D=m2d, opacities=leaves["opacities"],
+                                 shs=leaves.get("shs"), colors_precomp=leaves.get("colors_precomp"),
+                                 scales=leaves.get("scales"), rotations=leaves.get("rotations"),
+                                 cov3D_precomp=leaves.get("cov3D_precomp"), theta=theta, rho=rho)
+    (out[0] * sc.grad_color.to(DEV)).sum().add((out[2] * sc.grad_depth.to(DEV)).sum()).backward()
+    grads = {k: v.grad.cpu() for k, v in leaves.items()}
+    grads.update(means2D=m2d.grad.cpu(), theta=theta.grad.cpu(), rho=rho.grad.cpu())
+    oout, og = rasterize_autograd(inp, ost, sc.grad_color, sc.grad_depth, dtype=torch.float32, want_ambiguous=True)
+    ok = ~oout.aux["ambiguous"]
+    assert torch.equal(out[1].cpu(), oout.radii)
+    assert (out[0].cpu() - oout.color).abs().amax(0)[ok].max() <= 1e-4
+    assert (out[2].cpu() - oout.depth).abs()[0][ok].max() <= 1e-4 * max(1.0, oout.depth.max().item())
+    assert (out[3].cpu() - oout.opacity).abs()[0][ok].max() <= 1e-4
+    for k, ref in og.items():
+        got = grads[k].reshape(ref.shape).double()
+        ref = ref.double()
+        if ref.abs().max() == 0:
+            assert got.abs().max() == 0, k
+            continue
+        rel = ((got - ref).norm() / ref.norm()).item()
+        assert rel <= rtol, f"{k}: rel L2 {rel:.2e}"
+    return out, grads, oout, og
+
+
+@pytest.mark.parametrize("deg", [0, 1, 2, 3])
+def test_sh_colours(native_lib, deg):
+    sc = make_scene(3000, "fr3_office", seed=20 + deg, anisotropic=True)
+    g = torch.Generator().manual_seed(deg)
+    shs = 0.4 * torch.randn(3000, 16, 3, generator=g)
+    shs[:, 0] += 0.5
+    inp = dict(means3D=sc.means3D, opacities=sc.opacities, shs=shs, scales=sc.scales, rotations=sc.rotations)
+    _, grads, _, og = _run(sc, inp, _hip_st(sc, sh_degree=deg), scene_settings(sc, OracleSettings, sh_degree=deg))
+    # coefficients above the active degree receive exactly zero
+    n_active = (deg + 1) ** 2
+    if n_active < 16:
+        assert grads["shs"][:, n_active:].abs().max() == 0
+
+
+def test_cov3d_precomp_and_scale_modifier(native_lib):
+    sc = make_scene(3000, "fr3_office", seed=31, anisotropic=True)
+    cov = gs_oracle.cov3d_from_scale_rot(sc.scales, sc.rotations, torch.tensor(1.0))
+    inp = dict(means3D=sc.means3D, opacities=sc.opacities, colors_precomp=sc.colors, cov3D_precomp=cov)
+    _run(sc, inp, _hip_st(sc), scene_settings(sc, OracleSettings))
+    inp2 = dict(means3D=sc.means3D, opacities=sc.opacities, colors_precomp=sc.colors, scales=sc.scales,
+                rotations=sc.rotations)
+    _run(sc, inp2, _hip_st(sc, scale_modifier=1.7), scene_settings(sc, OracleSettings, scale_modifier=1.7))
+
+
+def test_fov_clamp_and_offscreen_gaussians(native_lib):
+    """spread 1.6 puts Gaussians beyond the 1.3 tanFoV guard (clamped Jacobian, frozen in the backward)."""
+    sc = make_scene(4000, "fr3_office", seed=41, spread=1.6, mean_radius_px=12.0)
+    inp = dict(means3D=sc.means3D, opacities=sc.opacities, colors_precomp=sc.colors,
+               scales=sc.scales.repeat(1, 3), rotations=sc.rotations)
+    _run(sc, inp, _hip_st(sc), scene_settings(sc, OracleSettings))
+
+
+def test_huge_and_tiny_gaussians(native_lib):
+    """A few Gaussians covering hundreds of tiles plus sub-pixel ones; odd image size (partial tiles)."""
+    intr = dict(fx=300.0, fy=310.0, cx=161.3, cy=117.9, W=325, H=237)
+    sc = make_scene(600, intr, seed=51)
+    scales = sc.scales.repeat(1, 3).clone()
+    scales[:5] *= 60.0
+    scales[5:200] *= 0.02
+    inp = dict(means3D=sc.means3D, opacities=sc.opacities, colors_precomp=sc.colors, scales=scales,
+               rotations=sc.rotations)
+    out, *_ = _run(sc, inp, _hip_st(sc), scene_settings(sc, OracleSettings))
+    assert out[0].shape == (3, 237, 325)
+
+
+def test_dense_tile_many_instances(native_lib):
+    """> 64 and > 4096 instances in one tile: multi-step walks and early termination."""
+    intr = dict(fx=200.0, fy=200.0, cx=32.0, cy=32.0, W=64, H=64)
+    sc = make_scene(30000, intr, seed=61, mean_radius_px=10.0)
+    inp = dict(means3D=sc.means3D, opacities=sc.opacities, colors_precomp=sc.colors,
+               scales=sc.scales.repeat(1, 3), rotations=sc.rotations)
+    _, _, oout, _ = _run(sc, inp, _hip_st(sc), scene_settings(sc, OracleSettings))
+    r = oout.aux["ranges"]
+    assert (r[:, 1] - r[:, 0]).max() > 4096
+
+
+def test_empty_and_degenerate_inputs(native_lib):
+    from monogs_amd.rasterizer import GaussianRasterizer
+    sc = make_scene(50, "fr3_office", seed=71, bg=(0.25, 0.5, 0.75))
+    st = _hip_st(sc)
+    # P = 0: background only
+    z = lambda *s: torch.zeros(*s, device=DEV)  # noqa: E731
+    out = GaussianRasterizer(st)(means3D=z(0, 3), means2D=z(0, 3), opacities=z(0, 1), colors_precomp=z(0, 3),
+                                 scales=z(0, 3), rotations=z(0, 4))
+    assert torch.allclose(out[0], torch.tensor([0.25, 0.5, 0.75], device=DEV)[:, None, None].expand(3, 480, 640))
+    assert out[3].abs().max() == 0 and out[1].numel() == 0
+    # everything behind the camera: num_rendered = 0
+    means = sc.means3D.clone().to(DEV)
+    behind = (torch.tensor([0.0, 0.0, -5.0]) - sc.t) @ sc.R
+    means[:] = behind.to(DEV)
+    m = means.clone().requires_grad_(True)
+    out = GaussianRasterizer(st)(means3D=m, means2D=torch.zeros_like(m), opacities=sc.opacities.to(DEV),
+                                 colors_precomp=sc.colors.to(DEV), scales=sc.scales.repeat(1, 3).to(DEV),
+                                 rotations=sc.rotations.to(DEV))
+    assert (out[1] == 0).all() and out[3].abs().max() == 0 and (out[4] == 0).all()
+    out[0].sum().backward()
+    assert m.grad.abs().max() == 0
+
+
+def test_mark_visible(native_lib):
+    from monogs_amd.rasterizer import GaussianRasterizer
+    sc = make_scene(5000, "fr3_office", seed=81, near_fraction=0.2)
+    st = _hip_st(sc)
+    vis = GaussianRasterizer(st).markVisible(sc.means3D.to(DEV)).cpu()
+    pv = sc.means3D @ sc.R.t() + sc.t
+    want = pv[:, 2] > 0.2
+    assert (vis != want).sum() <= 2        # float32 association differs from the matmul above
+
+
+class _Intr:
+    def __init__(self, k):
+        self.k = k
+        self.height, self.width = k["H"], k["W"]
+        m = cam.camera_matrices(torch.eye(3), torch.zeros(3), k["fx"], k["fy"], k["cx"], k["cy"], k["W"], k["H"])
+        self.projection_matrix = m.projmatrix_raw.to(DEV)
+        import math
+        self.FoVx, self.FoVy = 2 * math.atan(m.tanfovx), 2 * math.atan(m.tanfovy)
+
+
+def test_render_seam_end_to_end(native_lib):
+    """monogs_amd.renderer.render() with duck-typed camera objects: dict keys, isotropic scale expansion,
+    viewspace_points.grad, pose-delta gradients, and the (fixed) mask branch."""
+    from monogs_amd.renderer import render
+    sc = make_scene(4000, "fr3_office", seed=91)
+    intr = _Intr(sc.intr)
+    view_t = cam.world2view(sc.R, sc.t).transpose(0, 1).contiguous().to(DEV)
+    vp = types.SimpleNamespace(world_view_transform=view_t, camera_center=view_t.inverse()[3, :3],
+                               cam_rot_delta=torch.zeros(3, device=DEV, requires_grad=True),
+                               cam_trans_delta=torch.zeros(3, device=DEV, requires_grad=True))
+    leaf = lambda t: t.to(DEV).clone().requires_grad_(True)  # noqa: E731
+    means, rot, sca, opa, col = leaf(sc.means3D), leaf(sc.rotations), leaf(sc.scales), leaf(sc.opacities), leaf(sc.colors)
+    pkg = render(vp, intr, means, rot, sca, opa, col, sc.bg.to(DEV))
+    assert set(pkg) == {"render", "viewspace_points", "visibility_filter", "radii", "depth", "opacity", "n_touched"}
+    loss = (pkg["render"] * sc.grad_color.to(DEV)).sum() + (pkg["depth"] * sc.grad_depth.to(DEV)).sum()
+    loss.backward()
+    inp = dict(means3D=sc.means3D, opacities=sc.opacities, colors_precomp=sc.colors,
+               scales=sc.scales.repeat(1, 3), rotations=sc.rotations)
+    oout, og = rasterize_autograd(inp, scene_settings(sc, OracleSettings), sc.grad_color, sc.grad_depth,
+                                  dtype=torch.float32)
+    rel = lambda a, b: ((a.double() - b.double()).norm() / b.double().norm()).item()  # noqa: E731
+    assert rel(pkg["viewspace_points"].grad.cpu(), og["means2D"]) < 1e-3
+    assert rel(vp.cam_rot_delta.grad.cpu(), og["theta"]) < 1e-3
+    assert rel(vp.cam_trans_delta.grad.cpu(), og["rho"]) < 1e-3
+    assert rel(sca.grad.cpu(), og["scales"].sum(1, keepdim=True)) < 1e-3      # isotropic: grad of repeat(1,3)
+    assert torch.equal(pkg["visibility_filter"].cpu(), oout.radii > 0)
+    # mask branch
+    mask = torch.zeros(4000, dtype=torch.bool, device=DEV)
+    mask[::2] = True
+    pkg2 = render(vp, intr, means, rot, sca, opa, col, sc.bg.to(DEV), mask=mask)
+    assert pkg2["radii"].shape[0] == 2000 and pkg2["n_touched"].shape[0] == 2000
+
+
+def test_multiple_forwards_before_one_backward(native_lib):
+    """The mapper renders every window keyframe, sums the losses and calls backward once
+    (/root/reference/utils/slam_mapper.py:273-394): per-call scratch must not be shared."""
+    from monogs_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+    sc = make_scene(3000, "fr3_office", seed=101)
+    leaf = lambda t: t.to(DEV).clone().requires_grad_(True)  # noqa: E731
+    means, opa, col, rot = leaf(sc.means3D), leaf(sc.opacities), leaf(sc.colors), leaf(sc.rotations)
+    scales = leaf(sc.scales.repeat(1, 3))
+    total = 0
+    ref = torch.zeros_like(sc.means3D)
+    for i in range(3):
+        d = cam.se3_exp(torch.tensor([0.03 * i, -0.02 * i, 0.0, 0.0, 0.01 * i, 0.0]))
+        T = torch.eye(4)
+        T[:3, :3], T[:3, 3] = sc.R, sc.t
+        T = d @ T
+        sci = sc._replace(R=T[:3, :3].contiguous(), t=T[:3, 3].contiguous())
+        st = scene_settings(sci, GaussianRasterizationSettings, device=DEV)
+        out = GaussianRasterizer(st)(means3D=means, means2D=torch.zeros_like(means), opacities=opa,
+                                     colors_precomp=col, scales=scales, rotations=rot)
+        total = total + (out[0] * sc.grad_color.to(DEV)).sum() + (out[2] * sc.grad_depth.to(DEV)).sum()
+        _, og = rasterize_autograd(dict(means3D=sc.means3D, opacities=sc.opacities, colors_precomp=sc.colors,
+                                        scales=sc.scales.repeat(1, 3), rotations=sc.rotations),
+                                   scene_settings(sci, OracleSettings), sc.grad_color, sc.grad_depth,
+                                   dtype=torch.float32)
+        ref += og["means3D"]
+    total.backward()
+    assert ((means.grad.cpu() - ref).norm() / ref.norm()).item() < 1e-3

@@ -85,7 +85,8 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    distributed = "RANK" in os.environ and "MASTER_PORT" in os.environ     # launched by torch.distributed.run
+    if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
@@ -112,7 +113,7 @@ def main():
     rho = torch.zeros(3, device=dev, requires_grad=True)
     g_color, g_depth = sc.grad_color.to(dev), sc.grad_depth.to(dev)
     rasterizer = GaussianRasterizer(st)
-    bucket = GradBucket(params) if world > 1 else None
+    bucket = GradBucket(params) if distributed else None
     state = {}
 
     def step():
@@ -132,7 +133,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if distributed:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -147,7 +148,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     log(f"timed region: {dt / args.steps * 1e3:.3f} ms/step")
-    if world > 1:
+    if distributed:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -197,7 +198,7 @@ def main():
         cpu = cpu_baseline()
         log("cpu baseline", cpu)
 
-    if world > 1:
+    if distributed:
         dist.barrier()
         dist.destroy_process_group()
 

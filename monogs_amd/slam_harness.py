@@ -1,0 +1,270 @@
+"""A minimal tracking + mapping loop around ``render()`` for measuring the SLAM-level metric
+(tracking / mapping FPS, BASELINE.json configs 3-4) without the reference's control plane.
+
+This is measurement scaffolding on the CALLER's side of the boundary, not a re-implementation of
+MonoGS: no processes, queues, viewer, dataset parsers, densify/prune.  It reproduces the two hot
+loops that drive the rasteriser exactly as the reference does:
+
+* tracking  (/root/reference/utils/slam_tracker.py:83-193): pose-only Adam (rot 0.003, trans 0.001,
+  exposure 0.01 -- /root/reference/configs/mono/tum/base_config.yaml:46-48), <= ``tracking_itr_num``
+  iterations of render -> get_loss_tracking -> backward -> step -> update_pose, early exit when the
+  retraction step is < 1e-4;
+* mapping   (/root/reference/utils/slam_mapper.py:244-500): per iteration render every window keyframe,
+  sum get_loss_mapping, ONE backward, Adam step on the Gaussians and on the window poses.
+
+The camera objects are duck-typed stand-ins for the reference's CameraIntrinsics / CameraExtrinsics
+(/root/reference/utils/camera_utils.py:8-79,82-221).  Frames come from a seeded ground-truth map
+rendered by the same rasteriser (the datasets of configs 3-4 are not available offline).
+"""
+from __future__ import annotations
+
+import math
+import time
+from typing import List, Optional
+
+import torch
+
+from . import camera as cam
+from .knn import distCUDA2
+from .renderer import render
+from .slam_losses import get_loss_mapping, get_loss_tracking
+from .synthetic import make_scene
+
+
+class Intrinsics:
+    def __init__(self, k: dict, device):
+        self.k, self.device = dict(k), device
+        self.height, self.width = k["H"], k["W"]
+        m = cam.camera_matrices(torch.eye(3), torch.zeros(3), k["fx"], k["fy"], k["cx"], k["cy"], k["W"], k["H"])
+        self.projection_matrix = m.projmatrix_raw.to(device)        # transposed, as the reference's property
+        self.FoVx, self.FoVy = 2 * math.atan(m.tanfovx), 2 * math.atan(m.tanfovy)
+
+
+class Viewpoint:
+    def __init__(self, idx, rgb, depth, device, gt_R=None, gt_T=None):
+        self.frame_idx, self.device = idx, device
+        self.R = torch.eye(3, device=device)
+        self.T = torch.zeros(3, device=device)
+        self.R_gt, self.T_gt = gt_R, gt_T
+        self.rgb, self.depth = rgb, depth
+        self.mask = torch.ones_like(depth, dtype=torch.bool)
+        # edge mask stand-in (the reference thresholds a Scharr gradient, utils/camera_utils.py:185-216)
+        gray = rgb.mean(0)
+        gx = torch.zeros_like(gray)
+        gy = torch.zeros_like(gray)
+        gx[:, 1:-1] = gray[:, 2:] - gray[:, :-2]
+        gy[1:-1] = gray[2:] - gray[:-2]
+        mag = torch.sqrt(gx * gx + gy * gy)
+        self.grad_mask = mag > mag.median() * 1.1
+        z = lambda n, v=0.0: torch.nn.Parameter(torch.full((n,), v, device=device))  # noqa: E731
+        self.cam_rot_delta, self.cam_trans_delta = z(3), z(3)
+        self.exposure_a, self.exposure_b = z(1), z(1)
+
+    @property
+    def world_view_transform(self):
+        return cam.world2view(self.R, self.T).transpose(0, 1)
+
+    @property
+    def camera_center(self):
+        return self.world_view_transform.inverse()[3, :3]
+
+    def update_RT(self, R, t):
+        self.R, self.T = R.to(self.device), t.to(self.device)
+
+    def retract(self, thr=1e-4) -> bool:
+        """update_pose (/root/reference/utils/pose_utils.py:76-93) on device tensors."""
+        tau = torch.cat([self.cam_trans_delta.data, self.cam_rot_delta.data])
+        Tm = torch.eye(4, device=self.device)
+        Tm[:3, :3], Tm[:3, 3] = self.R, self.T
+        Tn = cam.se3_exp(tau) @ Tm
+        self.R, self.T = Tn[:3, :3], Tn[:3, 3]
+        conv = bool(tau.norm() < thr)
+        self.cam_rot_delta.data.zero_()
+        self.cam_trans_delta.data.zero_()
+        return conv
+
+
+class GaussianMap:
+    """Isotropic RGB map with the reference's activations
+    (/root/reference/gaussian_splatting/scene/gaussian_model.py:84-106)."""
+
+    def __init__(self, device):
+        self.device = device
+        e = lambda *s: torch.empty(*s, device=device)  # noqa: E731
+        self._xyz, self._rgb, self._opacity, self._scaling, self._rotation = e(0, 3), e(0, 3), e(0, 1), e(0, 1), e(0, 4)
+        self.optimizer: Optional[torch.optim.Optimizer] = None
+
+    get_xyz = property(lambda s: s._xyz)
+    get_features = property(lambda s: s._rgb)
+    get_opacity = property(lambda s: torch.sigmoid(s._opacity))
+    get_scaling = property(lambda s: torch.exp(s._scaling))
+    get_rotation = property(lambda s: torch.nn.functional.normalize(s._rotation))
+
+    def params(self):
+        return [self._xyz, self._rgb, self._opacity, self._scaling, self._rotation]
+
+    def extend_from_frame(self, vp: Viewpoint, intr: Intrinsics, downsample: int, point_size=0.05, init=False,
+                          render_opacity=None):
+        """Back-project a keyframe's depth into new Gaussians; scale from distCUDA2
+        (/root/reference/gaussian_splatting/scene/gaussian_model.py:121-319, simplified)."""
+        H, W, k = intr.height, intr.width, intr.k
+        valid = vp.depth > 0
+        if render_opacity is not None and not init:
+            valid = valid & (render_opacity[0] < 0.5)
+        idx = valid.reshape(-1).nonzero().squeeze(1)
+        g = torch.Generator(device="cpu").manual_seed(1000 + vp.frame_idx)
+        keep = torch.randperm(idx.numel(), generator=g)[: max(idx.numel() // downsample, 0)].to(self.device)
+        idx = idx[keep]
+        if idx.numel() < 4:
+            return 0
+        v, u = idx // W, idx % W
+        z = vp.depth.reshape(-1)[idx]
+        pc = torch.stack([(u.float() - k["cx"]) / k["fx"] * z, (v.float() - k["cy"]) / k["fy"] * z, z], dim=1)
+        pw = (pc - vp.T[None]) @ vp.R                     # R^T (p_c - t)
+        rgb = vp.rgb.reshape(3, -1)[:, idx].t().contiguous()
+        dist2 = torch.clamp_min(distCUDA2(pw.contiguous()), 1e-7) * point_size
+        scales = torch.log(torch.sqrt(dist2))[:, None]
+        rots = torch.zeros(idx.numel(), 4, device=self.device)
+        rots[:, 0] = 1
+        opac = torch.zeros(idx.numel(), 1, device=self.device)      # inverse_sigmoid(0.5)
+        new = [pw, rgb, opac, scales, rots]
+        old_state = self.optimizer.state_dict()["state"] if self.optimizer is not None else {}
+        cat = [torch.cat([o.detach(), n], 0).requires_grad_(True) for o, n in zip(self.params(), new)]
+        self._xyz, self._rgb, self._opacity, self._scaling, self._rotation = cat
+        lrs = [1.6e-4 * 6.0, 0.0025, 0.05, 0.001, 0.001]   # position/feature/opacity/scaling/rotation lrs of the reference
+        self.optimizer = torch.optim.Adam([{"params": [p], "lr": lr} for p, lr in zip(self.params(), lrs)], eps=1e-15)
+        # carry Adam moments of the old Gaussians over, zeros for the new ones (densification_postfix)
+        for i, p in enumerate(self.params()):
+            st = old_state.get(i)
+            if st is not None:
+                n_new = p.shape[0] - st["exp_avg"].shape[0]
+                pad = lambda t: torch.cat([t, torch.zeros(n_new, *t.shape[1:], device=self.device)], 0)  # noqa: E731
+                self.optimizer.state[p] = dict(step=st["step"], exp_avg=pad(st["exp_avg"]),
+                                               exp_avg_sq=pad(st["exp_avg_sq"]))
+        return idx.numel()
+
+
+def _render(vp, intr, gmap: GaussianMap, bg):
+    return render(vp, intr, gmap.get_xyz, gmap.get_rotation, gmap.get_scaling, gmap.get_opacity, gmap.get_features, bg)
+
+
+def make_sequence(n_frames: int, intrinsics="fr3_office", n_gaussians=60000, seed=11, device="cuda:0"):
+    """Ground-truth map + a smooth camera path; frames rendered by the rasteriser itself."""
+    sc = make_scene(n_gaussians, intrinsics, seed=seed, near_fraction=0.0, mean_radius_px=9.0, device=device)
+    intr = Intrinsics(sc.intr, device)
+    gt = GaussianMap(device)
+    gt._xyz, gt._rgb = sc.means3D, sc.colors
+    gt._opacity = torch.logit(sc.opacities.clamp(0.05, 0.95) * 0 + 0.9)     # mostly opaque surface-like splats
+    gt._scaling, gt._rotation = torch.log(sc.scales), sc.rotations
+    bg = torch.zeros(3, device=device)
+    T0 = torch.eye(4, device=device)
+    T0[:3, :3], T0[:3, 3] = sc.R, sc.t
+    frames: List[Viewpoint] = []
+    with torch.no_grad():
+        for i in range(n_frames):
+            d = cam.se3_exp(torch.tensor([0.004 * i, -0.002 * i, 0.001 * i, 0.0, 0.0015 * i, 0.0005 * i], device=device))
+            Tm = d @ T0
+            vp = Viewpoint(i, torch.zeros(3, intr.height, intr.width, device=device),
+                           torch.ones(intr.height, intr.width, device=device), device)
+            vp.update_RT(Tm[:3, :3], Tm[:3, 3])
+            pkg = _render(vp, intr, gt, bg)
+            depth = torch.where(pkg["opacity"][0] > 0.5, pkg["depth"][0] / pkg["opacity"][0].clamp_min(1e-6),
+                                torch.zeros_like(pkg["depth"][0]))
+            frames.append(Viewpoint(i, pkg["render"].clamp(0, 1), depth, device, gt_R=Tm[:3, :3], gt_T=Tm[:3, 3]))
+    return frames, intr
+
+
+def run_slam(n_frames=12, intrinsics="fr3_office", tracking_itr_num=100, mapping_itr_num=150, window_size=8,
+             kf_interval=4, init_itr_num=300, n_gaussians=60000, device="cuda:0", log=None):
+    """Returns a dict with tracking / mapping FPS, iterations and the trajectory error."""
+    frames, intr = make_sequence(n_frames, intrinsics, n_gaussians, device=device)
+    bg = torch.zeros(3, device=device)
+    gmap = GaussianMap(device)
+    window: List[Viewpoint] = []
+    stats = dict(track_s=0.0, track_iters=0, tracked=0, map_s=0.0, map_iters=0, keyframes=0, renders=0)
+
+    def sync():
+        torch.cuda.synchronize()
+
+    def map_window(iters, init=False):
+        pose_params = []
+        for vp in window[1:] if len(window) > 1 else []:
+            pose_params += [{"params": [vp.cam_rot_delta], "lr": 0.003 * 0.5},
+                            {"params": [vp.cam_trans_delta], "lr": 0.001 * 0.5},
+                            {"params": [vp.exposure_a], "lr": 0.01}, {"params": [vp.exposure_b], "lr": 0.01}]
+        kf_opt = torch.optim.Adam(pose_params) if pose_params else None
+        for _ in range(iters):
+            loss = 0
+            for vp in window:
+                pkg = _render(vp, intr, gmap, bg)
+                loss = loss + get_loss_mapping(pkg["render"], pkg["depth"], vp, init=init)
+                stats["renders"] += 1
+            loss.backward()
+            with torch.no_grad():
+                gmap.optimizer.step()
+                gmap.optimizer.zero_grad(set_to_none=True)
+                if kf_opt is not None:
+                    kf_opt.step()
+                    kf_opt.zero_grad(set_to_none=True)
+                    for vp in window[1:]:
+                        vp.retract()
+            stats["map_iters"] += 1
+
+    for i, vp in enumerate(frames):
+        if i == 0:
+            vp.update_RT(vp.R_gt, vp.T_gt)
+            sync(); t0 = time.perf_counter()
+            gmap.extend_from_frame(vp, intr, downsample=32, init=True)
+            window.append(vp)
+            map_window(init_itr_num, init=True)
+            sync(); stats["map_s"] += time.perf_counter() - t0
+            stats["keyframes"] += 1
+            continue
+        # ---- tracking (pose only; the Gaussians still require grad, as in the reference)
+        prev = frames[i - 1]
+        vp.update_RT(prev.R, prev.T)
+        opt = torch.optim.Adam([{"params": [vp.cam_rot_delta], "lr": 0.003}, {"params": [vp.cam_trans_delta], "lr": 0.001},
+                                {"params": [vp.exposure_a], "lr": 0.01}, {"params": [vp.exposure_b], "lr": 0.01}])
+        sync(); t0 = time.perf_counter()
+        for it in range(tracking_itr_num):
+            pkg = _render(vp, intr, gmap, bg)
+            opt.zero_grad()
+            loss = get_loss_tracking(pkg["render"], pkg["depth"], pkg["opacity"], vp)
+            loss.backward()
+            with torch.no_grad():
+                opt.step()
+                conv = vp.retract()
+            stats["track_iters"] += 1
+            stats["renders"] += 1
+            if conv:
+                break
+        sync(); stats["track_s"] += time.perf_counter() - t0
+        stats["tracked"] += 1
+        for p in gmap.params():
+            p.grad = None
+        # ---- keyframe + mapping
+        if i % kf_interval == 0:
+            sync(); t0 = time.perf_counter()
+            with torch.no_grad():
+                pkg = _render(vp, intr, gmap, bg)
+            gmap.extend_from_frame(vp, intr, downsample=64, render_opacity=pkg["opacity"])
+            window.append(vp)
+            if len(window) > window_size:
+                window.pop(1)
+            map_window(mapping_itr_num)
+            sync(); stats["map_s"] += time.perf_counter() - t0
+            stats["keyframes"] += 1
+        if log:
+            log(f"frame {i}: P={gmap.get_xyz.shape[0]} track_iters={stats['track_iters']} kf={stats['keyframes']}")
+
+    err = torch.stack([(-(f.R.t() @ f.T) + (f.R_gt.t() @ f.T_gt)).norm() for f in frames[1:]])
+    out = dict(stats)
+    out.update(frames=n_frames, gaussians=int(gmap.get_xyz.shape[0]), width=intr.width, height=intr.height,
+               tracking_fps=stats["tracked"] / max(stats["track_s"], 1e-9),
+               tracking_iters_per_s=stats["track_iters"] / max(stats["track_s"], 1e-9),
+               mapping_iters_per_s=stats["map_iters"] / max(stats["map_s"], 1e-9),
+               mapping_kf_per_s=stats["keyframes"] / max(stats["map_s"], 1e-9),
+               ate_rmse_m=float(torch.sqrt((err ** 2).mean())),
+               config=dict(tracking_itr_num=tracking_itr_num, mapping_itr_num=mapping_itr_num,
+                           window_size=window_size, kf_interval=kf_interval, init_itr_num=init_itr_num))
+    return out

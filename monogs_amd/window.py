@@ -27,20 +27,36 @@ def shard_keyframes(n_keyframes: int, rank: int, world: int) -> List[int]:
     return [k for k in range(n_keyframes) if k % world == rank]
 
 
-class GradBucket:
-    """One flat [P, C] float32 buffer holding every Gaussian gradient column, reduced in one call."""
+# Above this many bytes the gradients are reduced in place, tensor by tensor (5 large collectives),
+# instead of being packed into one bucket: at 2 M Gaussians the pack + unpack copies (2 x 96 MB) cost
+# more than four extra collective launches; small SLAM maps (a few MB) keep the single latency-bound message.
+PER_TENSOR_BYTES = 32 << 20
 
-    def __init__(self, params: Sequence[torch.Tensor], extra_cols: int = 0):
+
+class GradBucket:
+    """One flat [P, C] float32 buffer holding every Gaussian gradient column, reduced in one call
+    (or, for large maps, the gradient tensors themselves reduced in place)."""
+
+    def __init__(self, params: Sequence[torch.Tensor], extra_cols: int = 0, per_tensor: Optional[bool] = None):
         self.params = list(params)
         P = self.params[0].shape[0]
         self.widths = [int(p.numel() // P) for p in self.params]
         self.extra_cols = extra_cols
-        self.buf = torch.zeros(P, sum(self.widths) + extra_cols, dtype=torch.float32,
-                               device=self.params[0].device)
+        total_bytes = 4 * P * (sum(self.widths) + extra_cols)
+        self.per_tensor = (total_bytes > PER_TENSOR_BYTES) if per_tensor is None else per_tensor
+        cols = extra_cols if self.per_tensor else sum(self.widths) + extra_cols
+        self.buf = torch.zeros(P, cols, dtype=torch.float32, device=self.params[0].device)
 
     def pack(self, extra: Optional[torch.Tensor] = None):
         c = 0
         P = self.buf.shape[0]
+        if self.per_tensor:
+            for p in self.params:
+                if p.grad is None:
+                    p.grad = torch.zeros_like(p)
+            if self.extra_cols:
+                self.buf.zero_() if extra is None else self.buf.copy_(extra)
+            return
         for p, w in zip(self.params, self.widths):
             g = p.grad
             if g is None:
@@ -56,6 +72,8 @@ class GradBucket:
 
     def unpack(self) -> Optional[torch.Tensor]:
         c = 0
+        if self.per_tensor:
+            return self.buf if self.extra_cols else None
         for p, w in zip(self.params, self.widths):
             g = self.buf[:, c:c + w].reshape(p.shape)
             if p.grad is None:
@@ -66,9 +84,18 @@ class GradBucket:
         return self.buf[:, c:] if self.extra_cols else None
 
     def all_reduce(self, group=None, async_op: bool = False):
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-            return dist.all_reduce(self.buf, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
-        return None
+        if not (dist.is_available() and dist.is_initialized()):
+            return None
+        if self.per_tensor:
+            works = [dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=group, async_op=True) for p in self.params]
+            if self.extra_cols:
+                works.append(dist.all_reduce(self.buf, op=dist.ReduceOp.SUM, group=group, async_op=True))
+            if async_op:
+                return works
+            for w in works:
+                w.wait()
+            return None
+        return dist.all_reduce(self.buf, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
 
 
 def allreduce_window_grads(params: Sequence[torch.Tensor], viewspace_grad_norm: Optional[torch.Tensor] = None,

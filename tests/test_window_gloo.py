@@ -25,7 +25,7 @@ def _keyframe_grads(P, k):
         (torch.rand(P, generator=g) > 0.5).float(), torch.randint(0, 30, (P,), generator=g).float()
 
 
-def _worker(rank, world, port, P, n_kf, out):
+def _worker(rank, world, port, P, n_kf, out, per_tensor):
     sys.path.insert(0, ROOT)
     from monogs_amd.window import allreduce_window_grads, shard_keyframes
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -44,7 +44,9 @@ def _worker(rank, world, port, P, n_kf, out):
         norm += n
         vis += v
         maxr = torch.maximum(maxr, r)
-    _, norm_s, vis_s, maxr_s = allreduce_window_grads(params, norm, vis, maxr)
+    from monogs_amd.window import GradBucket
+    bucket = GradBucket(params, extra_cols=2, per_tensor=per_tensor)
+    _, norm_s, vis_s, maxr_s = allreduce_window_grads(params, norm, vis, maxr, bucket=bucket)
     if rank == 0:
         torch.save(dict(grads=[p.grad for p in params], norm=norm_s.clone(), vis=vis_s.clone(), maxr=maxr_s), out)
     dist.barrier()
@@ -59,10 +61,11 @@ def test_shard_keyframes_partition():
     assert shard_keyframes(8, 3, 8) == [3]
 
 
-def test_two_rank_allreduce_equals_serial_sum(tmp_path):
+@pytest.mark.parametrize("per_tensor", [False, True])
+def test_two_rank_allreduce_equals_serial_sum(tmp_path, per_tensor):
     P, n_kf, world = 257, 5, 2
     out = str(tmp_path / "r0.pt")
-    mp.spawn(_worker, args=(world, _free_port(), P, n_kf, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), P, n_kf, out, per_tensor), nprocs=world, join=True)
     got = torch.load(out)
     want = [torch.zeros(P, w) for w in (3, 3, 1, 1, 4)]
     norm, vis, maxr = torch.zeros(P), torch.zeros(P), torch.zeros(P)

@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Tracking + mapping FPS of the two SLAM hot loops on a synthetic sequence (BASELINE configs 3-4
+stand-in; the TUM / Replica sequences are not available offline).  Prints one JSON line.
+  python tools/slam_bench.py --config tum      # 640x480, tracking 100 / mapping 150 / window 8 / kf 5
+  python tools/slam_bench.py --config replica  # 1200x680, tracking 100 / mapping 150 / window 10 / kf 4
+"""
+import argparse
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+CONFIGS = {
+    # /root/reference/configs/mono/tum/base_config.yaml:24-33
+    "tum": dict(intrinsics="fr3_office", tracking_itr_num=100, mapping_itr_num=150, window_size=8, kf_interval=5),
+    # /root/reference/configs/rgbd/replica/base_config.yaml:39-48
+    "replica": dict(intrinsics="replica", tracking_itr_num=100, mapping_itr_num=150, window_size=10, kf_interval=4),
+}
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="tum", choices=list(CONFIGS))
+    ap.add_argument("--frames", type=int, default=11)
+    ap.add_argument("--init-iters", type=int, default=300)
+    ap.add_argument("--mapping-iters", type=int, default=None)
+    ap.add_argument("--gaussians", type=int, default=60000)
+    a = ap.parse_args()
+    from monogs_amd.slam_harness import run_slam
+    cfg = dict(CONFIGS[a.config])
+    if a.mapping_iters is not None:
+        cfg["mapping_itr_num"] = a.mapping_iters
+    out = run_slam(n_frames=a.frames, init_itr_num=a.init_iters, n_gaussians=a.gaussians,
+                   log=lambda s: print("[slam]", s, file=sys.stderr, flush=True), **cfg)
+    out["workload"] = f"synthetic {a.config}-like sequence, {a.frames} frames"
+    print(json.dumps(out))

@@ -164,7 +164,7 @@ def main():
         fw = [d for d in sink if d["kind"] == "forward"]
         bw = [d for d in sink if d["kind"] == "backward"]
         avg = lambda rows, k: sum(r[k] for r in rows) / max(1, len(rows))  # noqa: E731
-        for k in ("preprocess_ms", "scan_ms", "duplicate_ms", "sort_ms", "ranges_ms", "blend_fwd_ms"):
+        for k in ("preprocess_ms", "depth_sort_ms", "scan_ms", "duplicate_ms", "sort_ms", "ranges_ms", "blend_fwd_ms"):
             stages[k] = round(avg(fw, k), 4)
         for k in ("blend_bwd_ms", "geom_bwd_ms"):
             stages[k] = round(avg(bw, k), 4)

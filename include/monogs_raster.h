@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define MGS_ABI_VERSION 1
+#define MGS_ABI_VERSION 2
 #define MGS_TILE 16 /* tile edge in pixels; ranges are per 16x16 tile */
 
 /* GaussianRasterizationSettings, minus `prefiltered` / `debug` which are call flags
@@ -63,6 +63,7 @@ typedef struct mgs_camera {
  * Passing a non-NULL mgs_timing makes the call synchronise `stream` before returning. */
 typedef struct mgs_timing {
     float preprocess_ms;
+    float depth_sort_ms;
     float scan_ms;
     float duplicate_ms;
     float sort_ms;
@@ -82,8 +83,8 @@ size_t mgs_image_bytes(int32_t width, int32_t height);
 size_t mgs_binning_bytes(uint64_t num_rendered, int32_t width, int32_t height);
 size_t mgs_backward_bytes(int32_t P);
 
-/* Forward, stage 1: per-Gaussian projection (cull, covariance, radius, tile rectangle, colour) and the
- * prefix sum of tiles touched.  Writes radii[P] and the geometry scratch, then copies the total number
+/* Forward, stage 1: per-Gaussian projection (cull, covariance, radius, tile rectangle, colour), the depth
+ * order of the Gaussians and the prefix sum of tiles touched in that order.  Writes radii[P] and the geometry scratch, then copies the total number
  * of (Gaussian, tile) instances to *num_rendered [host] -- this synchronises `stream`, exactly as the
  * upstream forward does, because the caller must size the binning scratch from it.
  * Exactly one of (shs, colors_precomp) and exactly one of ((scales, rotations), cov3D_precomp) is non-NULL. */
@@ -99,7 +100,7 @@ int mgs_forward_preprocess(const mgs_camera* cam, int32_t P,
                            uint64_t* num_rendered /* [host] */,
                            mgs_timing* timing /* [host] or NULL */, void* stream);
 
-/* Forward, stage 2: duplicate-with-keys, sort by (tile, depth), per-tile ranges, front-to-back blend.
+/* Forward, stage 2: duplicate (in depth order), stable grouping by tile, per-tile ranges, front-to-back blend.
  * Outputs: color[3,H,W], depth[1,H,W] (sum z.alpha.T), opacity[1,H,W] (1 - T), n_touched[P]
  * (zeroed here, then incremented per pixel where the Gaussian is blended with T.(1-alpha) > 0.5). */
 int mgs_forward_render(const mgs_camera* cam, int32_t P, uint64_t num_rendered,

@@ -11,7 +11,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmonogs_raster.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 c_float_p = C.c_void_p   # device pointers travel as integers (tensor.data_ptr())
 
@@ -28,7 +28,7 @@ class MgsCamera(C.Structure):
 
 class MgsTiming(C.Structure):
     _fields_ = [(n, C.c_float) for n in (
-        "preprocess_ms", "scan_ms", "duplicate_ms", "sort_ms", "ranges_ms", "blend_fwd_ms",
+        "preprocess_ms", "depth_sort_ms", "scan_ms", "duplicate_ms", "sort_ms", "ranges_ms", "blend_fwd_ms",
         "blend_bwd_ms", "geom_bwd_ms")]
 
     def as_dict(self):

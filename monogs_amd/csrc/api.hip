@@ -23,24 +23,27 @@ static inline char* take(char*& p, size_t bytes) {
     return r;
 }
 
-size_t GeometryState::bytes(int P) {
-    char* p = nullptr;
-    take(p, (size_t)P * REC_FLOATS * sizeof(float));
-    take(p, (size_t)P * sizeof(uint32_t));
-    take(p, (size_t)P * sizeof(uint32_t));
-    take(p, ((size_t)scan_nblocks(P) + 64) * sizeof(uint32_t));
-    take(p, (size_t)P * 4);
-    return (size_t)(p - (char*)nullptr) + 256;
-}
 GeometryState GeometryState::carve(void* base, int P) {
     char* p = (char*)align_up((size_t)base, 256);
     GeometryState g;
     g.rec = (float*)take(p, (size_t)P * REC_FLOATS * sizeof(float));
     g.tiles_touched = (uint32_t*)take(p, (size_t)P * sizeof(uint32_t));
+    g.depth_key = (uint32_t*)take(p, (size_t)P * sizeof(uint32_t));
+    g.depth_alt = (uint32_t*)take(p, (size_t)P * sizeof(uint32_t));
+    g.iota = (uint32_t*)take(p, (size_t)P * sizeof(uint32_t));
+    g.iota_alt = (uint32_t*)take(p, (size_t)P * sizeof(uint32_t));
+    g.perm = radix_result_in_b(32) ? g.iota_alt : g.iota;
     g.point_offsets = (uint32_t*)take(p, (size_t)P * sizeof(uint32_t));
     g.scan_blocks = (uint32_t*)take(p, ((size_t)scan_nblocks(P) + 64) * sizeof(uint32_t));
     g.clamped = (uint8_t*)take(p, (size_t)P * 4);
+    g.sort_temp_bytes = mgs::sort_temp_bytes((uint64_t)P, 32);
+    g.sort_temp = take(p, g.sort_temp_bytes);
+    g.end = p;
     return g;
+}
+size_t GeometryState::bytes(int P) {
+    const GeometryState g = carve(nullptr, P);
+    return (size_t)g.end + 256;
 }
 
 size_t ImageState::bytes(int W, int H) {
@@ -59,17 +62,20 @@ ImageState ImageState::carve(void* base, int W, int H) {
 
 size_t BinningState::bytes(uint64_t R, int W, int H) {
     const size_t r = (size_t)(R ? R : 1);
-    return align_up(r * 8, 256) * 2 + align_up(r * 4, 256) * 2 + align_up(mgs::sort_temp_bytes(R, key_bits(W, H)), 256) + 256;
+    return align_up(r * 4, 256) * 4 + align_up(mgs::sort_temp_bytes(R, tile_bits(W, H)), 256) + 256;
 }
 BinningState BinningState::carve(void* base, uint64_t R, int W, int H) {
     const size_t r = (size_t)(R ? R : 1);
     char* p = (char*)align_up((size_t)base, 256);
     BinningState b;
-    b.keys_unsorted = (uint64_t*)take(p, r * 8);
-    b.keys_sorted = (uint64_t*)take(p, r * 8);
-    b.vals_unsorted = (uint32_t*)take(p, r * 4);
-    b.vals_sorted = (uint32_t*)take(p, r * 4);
-    b.sort_temp_bytes = mgs::sort_temp_bytes(R, key_bits(W, H));
+    b.keys_a = (uint32_t*)take(p, r * 4);
+    b.keys_b = (uint32_t*)take(p, r * 4);
+    b.vals_a = (uint32_t*)take(p, r * 4);
+    b.vals_b = (uint32_t*)take(p, r * 4);
+    const bool in_b = radix_result_in_b(tile_bits(W, H));
+    b.keys_sorted = in_b ? b.keys_b : b.keys_a;
+    b.vals_sorted = in_b ? b.vals_b : b.vals_a;
+    b.sort_temp_bytes = mgs::sort_temp_bytes(R, tile_bits(W, H));
     b.sort_temp = take(p, b.sort_temp_bytes);
     return b;
 }
@@ -153,6 +159,8 @@ int mgs_forward_preprocess(const mgs_camera* cam, int32_t P, const float* means3
     if (int rc = launch_preprocess_forward(*cam, P, means3D, shs, colors_precomp, opacities, scales, rotations,
                                            cov3D_precomp, g, radii, s)) return rc;
     tm.mark();
+    if (int rc = launch_depth_sort(g, P, s)) return rc;
+    tm.mark();
     if (int rc = launch_scan(g, P, s)) return rc;
     tm.mark();
     uint32_t total = 0;
@@ -161,7 +169,8 @@ int mgs_forward_preprocess(const mgs_camera* cam, int32_t P, const float* means3
     *num_rendered = total;
     if (timing) {
         timing->preprocess_ms = tm.ms(0);
-        timing->scan_ms = tm.ms(1);
+        timing->depth_sort_ms = tm.ms(1);
+        timing->scan_ms = tm.ms(2);
     }
     return 0;
 }
@@ -186,7 +195,7 @@ int mgs_forward_render(const mgs_camera* cam, int32_t P, uint64_t R, void* geome
         if (int rc = launch_duplicate(*cam, P, g, b, s)) return rc;
     }
     tm.mark();
-    if (int rc = launch_sort(b, R, key_bits(W, H), s)) return rc;
+    if (int rc = launch_sort(b, R, tile_bits(W, H), s)) return rc;
     tm.mark();
     if (int rc = launch_ranges(b, R, img, tiles_x(W) * tiles_y(H), s)) return rc;
     tm.mark();

@@ -42,9 +42,17 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 struct GeometryState {
     float* rec;               // [P][16]
     uint32_t* tiles_touched;  // [P]
-    uint32_t* point_offsets;  // [P] inclusive scan of tiles_touched
+    uint32_t* depth_key;      // [P] float32 bits of the view-space depth (0xFFFFFFFF when culled); sort input
+    uint32_t* depth_alt;      // [P] ping-pong partner of depth_key
+    uint32_t* iota;           // [P] 0..P-1; sort input
+    uint32_t* iota_alt;       // [P] ping-pong partner of iota
+    uint32_t* perm;           // = iota or iota_alt: Gaussian index in (depth, index) order -- culled ones last
+    uint32_t* point_offsets;  // [P] inclusive scan of tiles_touched[perm[i]]
     uint32_t* scan_blocks;    // [scan_nblocks(P) + 64]
     uint8_t* clamped;         // [P][4] SH colour clamp flags
+    void* sort_temp;          // depth sort scratch
+    size_t sort_temp_bytes;
+    char* end;                // one past the last carved byte
     static size_t bytes(int P);
     static GeometryState carve(void* base, int P);
 };
@@ -58,10 +66,12 @@ struct ImageState {
 };
 
 struct BinningState {
-    uint64_t* keys_unsorted;
-    uint64_t* keys_sorted;
-    uint32_t* vals_unsorted;
-    uint32_t* vals_sorted;     // "point_list": Gaussian index per instance, blend order
+    uint32_t* keys_a;          // tile id per instance, emitted in (depth, index) order; sort input
+    uint32_t* vals_a;
+    uint32_t* keys_b;          // ping-pong partners
+    uint32_t* vals_b;
+    uint32_t* keys_sorted;     // = keys_a or keys_b: tile ids grouped by tile (stable)
+    uint32_t* vals_sorted;     // = vals_a or vals_b: "point_list", Gaussian index per instance in blend order
     void* sort_temp;
     size_t sort_temp_bytes;
     static size_t bytes(uint64_t R, int W, int H);
@@ -73,11 +83,11 @@ inline int scan_nblocks(int P) { return (P + SCAN_ITEMS - 1) / SCAN_ITEMS; }
 
 inline int tiles_x(int W) { return (W + TILE - 1) / TILE; }
 inline int tiles_y(int H) { return (H + TILE - 1) / TILE; }
-inline int key_bits(int W, int H) {      // bits of (tile_id << 32 | depth) that can be set
+inline int tile_bits(int W, int H) {     // bits of the tile id that can be set
     uint32_t n = (uint32_t)(tiles_x(W) * tiles_y(H));
     int b = 0;
     while ((1u << b) < n && b < 31) ++b;
-    return 32 + (b == 0 ? 1 : b);
+    return b == 0 ? 1 : b;
 }
 
 // ---- error plumbing --------------------------------------------------------------------------
@@ -100,7 +110,12 @@ int launch_preprocess_forward(const mgs_camera& cam, int P, const float* means3D
                               const GeometryState& g, int32_t* radii, hipStream_t s);
 int launch_scan(const GeometryState& g, int P, hipStream_t s);
 int launch_duplicate(const mgs_camera& cam, int P, const GeometryState& g, const BinningState& b, hipStream_t s);
-size_t sort_temp_bytes(uint64_t R, int bits);
+size_t sort_temp_bytes(uint64_t n, int bits);
+size_t radix_temp_bytes(uint64_t n, int bits);
+bool radix_result_in_b(int bits);
+int radix_sort_pairs(uint32_t* ka, uint32_t* va, uint32_t* kb, uint32_t* vb, uint64_t n, int bits, void* temp,
+                     hipStream_t s);
+int launch_depth_sort(const GeometryState& g, int P, hipStream_t s);
 int launch_sort(const BinningState& b, uint64_t R, int bits, hipStream_t s);
 int launch_ranges(const BinningState& b, uint64_t R, const ImageState& img, int ntiles, hipStream_t s);
 int launch_blend_forward(const mgs_camera& cam, const GeometryState& g, const BinningState& b,

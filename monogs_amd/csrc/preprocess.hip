@@ -142,6 +142,8 @@ struct PreArgs {
     const float *V, *PM, *campos;
     float* rec;
     uint32_t* tiles_touched;
+    uint32_t* depth_key;
+    uint32_t* iota;
     uint8_t* clamped;
     int32_t* radii;
     float tanfovx, tanfovy, focal_x, focal_y, mod;
@@ -153,6 +155,8 @@ __global__ void __launch_bounds__(256) preprocess_forward_kernel(PreArgs a) {
     if (idx >= a.P) return;
     a.radii[idx] = 0;
     a.tiles_touched[idx] = 0;
+    a.depth_key[idx] = 0xFFFFFFFFu;       // culled Gaussians sort behind every visible one
+    a.iota[idx] = (uint32_t)idx;
 
     Cam c;
     load_cam(c, a.V, a.PM, nullptr, a.campos);
@@ -233,6 +237,7 @@ __global__ void __launch_bounds__(256) preprocess_forward_kernel(PreArgs a) {
     rec[3] = make_float4(p.cxx, p.cxy, p.cyy, radius);
     a.radii[idx] = (int)radius;
     a.tiles_touched[idx] = (uint32_t)ntile;
+    a.depth_key[idx] = __float_as_uint(pv[2]);   // > 0.2, so the bit pattern orders like the value
 }
 
 int launch_preprocess_forward(const mgs_camera& cam, int P, const float* means3D, const float* shs,
@@ -243,7 +248,8 @@ int launch_preprocess_forward(const mgs_camera& cam, int P, const float* means3D
     a.means3D = means3D; a.shs = shs; a.colors = colors_precomp; a.opacities = opacities;
     a.scales = scales; a.rotations = rotations; a.cov3D = cov3D_precomp;
     a.V = cam.viewmatrix; a.PM = cam.projmatrix; a.campos = cam.campos;
-    a.rec = g.rec; a.tiles_touched = g.tiles_touched; a.clamped = g.clamped; a.radii = radii;
+    a.rec = g.rec; a.tiles_touched = g.tiles_touched; a.depth_key = g.depth_key; a.iota = g.iota;
+    a.clamped = g.clamped; a.radii = radii;
     a.tanfovx = cam.tanfovx; a.tanfovy = cam.tanfovy;
     a.focal_x = (float)cam.image_width / (2.0f * cam.tanfovx);
     a.focal_y = (float)cam.image_height / (2.0f * cam.tanfovy);

@@ -1,0 +1,277 @@
+// Stable LSD radix sort of (uint32 key, uint32 value) pairs, hand-written for gfx950 (wave64).
+//
+// Used twice per forward (binning.hip): the P Gaussians by their 32 depth bits, then the R
+// (tile id, Gaussian index) instances by tile id.  Replaces upstream's cub::DeviceRadixSort call
+// (SURVEY.md section 2.1 K4).
+//
+// Structure ("one sweep" per 8-bit digit):
+//   * ONE histogram kernel reads the keys once and counts every digit of every pass; a tiny kernel
+//     turns the counts into exclusive global bases;
+//   * per pass ONE kernel.  A workgroup (256 threads = 4 waves) takes a tile of 4096 pairs, ranks
+//     them stably (wave64 __ballot match per digit bit + per-wave LDS counters), publishes its 256
+//     digit counts, obtains the sum of the counts of all EARLIER tiles by decoupled look-back, lays
+//     the tile out digit-by-digit in LDS and writes each digit's run to its final place (coalesced
+//     runs instead of a 256-way scatter).
+// Inter-workgroup protocol (MI355X_MICROARCH.md "Workgroup dispatch ... visibility", form R2): every
+// status word is a self-describing 8-byte granule {flag:2, count:62} written by ONE agent-scope
+// relaxed atomic store and polled with agent-scope relaxed atomic loads; no other data crosses
+// workgroups, so no fence is needed.  Tile ids are handed out by an atomic ticket, so a tile only
+// ever waits for tiles that already started (placement-independent forward progress); every spin is
+// bounded and raises an error flag instead of hanging.
+#include "common.h"
+
+namespace mgs {
+
+constexpr int RS_THREADS = 256;
+constexpr int RS_WAVES = RS_THREADS / WAVE;
+constexpr int RS_ITEMS = 16;
+constexpr int RS_TILE = RS_THREADS * RS_ITEMS;     // 4096 pairs per workgroup
+constexpr int RS_RADIX = 256;
+constexpr int RS_MAX_PASSES = 4;
+constexpr uint64_t RS_FLAG_LOCAL = 1ull << 62;     // count of this tile only
+constexpr uint64_t RS_FLAG_GLOBAL = 2ull << 62;    // inclusive count over tiles 0..this
+constexpr uint64_t RS_COUNT_MASK = (1ull << 62) - 1;
+constexpr uint32_t RS_SPIN_LIMIT = 1u << 24;
+
+static inline int rs_passes(int bits) { return (bits + 7) / 8; }
+static inline uint32_t rs_tiles(uint64_t n) { return (uint32_t)((n + RS_TILE - 1) / RS_TILE); }
+
+// temp layout: [hist: RS_MAX_PASSES*256 u32][base: RS_MAX_PASSES*256 u32][tickets: RS_MAX_PASSES u32]
+//              [error: 1 u32][pad][status: passes * tiles * 256 u64]
+struct RsTemp {
+    uint32_t* hist;
+    uint32_t* base;
+    uint32_t* tickets;
+    uint32_t* error;
+    uint64_t* status;
+    size_t zero_bytes;     // everything from `hist` that must be zero before the sort
+};
+static RsTemp rs_carve(void* temp, uint64_t n, int bits) {
+    char* p = (char*)align_up((size_t)temp, 256);
+    RsTemp t;
+    t.hist = (uint32_t*)p;
+    t.base = t.hist + RS_MAX_PASSES * RS_RADIX;
+    t.tickets = t.base + RS_MAX_PASSES * RS_RADIX;
+    t.error = t.tickets + RS_MAX_PASSES;
+    char* q = (char*)align_up((size_t)(t.error + 1), 256);
+    t.status = (uint64_t*)q;
+    const size_t status_bytes = (size_t)rs_passes(bits) * rs_tiles(n) * RS_RADIX * sizeof(uint64_t);
+    t.zero_bytes = (size_t)(q - p) + status_bytes;
+    return t;
+}
+size_t radix_temp_bytes(uint64_t n, int bits) {
+    if (n == 0) return 256;
+    const RsTemp t = rs_carve(nullptr, n, bits);
+    return t.zero_bytes + 512;
+}
+
+// ------------------------------------------------------------------------------------------------
+struct RsShifts { int npasses; };
+
+__global__ void __launch_bounds__(RS_THREADS) rs_hist_kernel(const uint32_t* __restrict__ keys, uint32_t n, int npasses,
+                                                             uint32_t* __restrict__ hist) {
+    __shared__ uint32_t lh[RS_MAX_PASSES][RS_RADIX];
+    for (int i = threadIdx.x; i < RS_MAX_PASSES * RS_RADIX; i += RS_THREADS) (&lh[0][0])[i] = 0;
+    __syncthreads();
+    for (uint32_t i = blockIdx.x * RS_THREADS + threadIdx.x; i < n; i += gridDim.x * RS_THREADS) {
+        const uint32_t k = keys[i];
+        for (int p = 0; p < npasses; ++p) atomicAdd(&lh[p][(k >> (8 * p)) & 0xFF], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < npasses * RS_RADIX; i += RS_THREADS) {
+        const uint32_t c = (&lh[0][0])[i];
+        if (c) atomicAdd(hist + i, c);
+    }
+}
+
+// one workgroup per pass: exclusive scan of its 256 bins
+__global__ void __launch_bounds__(RS_RADIX) rs_scan_kernel(const uint32_t* __restrict__ hist, uint32_t* __restrict__ base) {
+    __shared__ uint32_t wsum[RS_RADIX / WAVE];
+    const int p = blockIdx.x, d = threadIdx.x, lane = d & 63, wv = d >> 6;
+    const uint32_t c = hist[p * RS_RADIX + d];
+    uint32_t v = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t u = __shfl_up(v, o, 64);
+        if (lane >= o) v += u;
+    }
+    if (lane == 63) wsum[wv] = v;
+    __syncthreads();
+    uint32_t add = 0;
+    for (int w = 0; w < wv; ++w) add += wsum[w];
+    base[p * RS_RADIX + d] = add + v - c;
+}
+
+struct RsPassArgs {
+    const uint32_t* kin;
+    uint32_t* kout;
+    const uint32_t* vin;
+    uint32_t* vout;
+    uint32_t n;
+    int shift;
+    const uint32_t* base;     // [256] exclusive global base of each digit for this pass
+    uint64_t* status;         // [tiles][256]
+    uint32_t* ticket;
+    uint32_t* error;
+};
+
+__global__ void __launch_bounds__(RS_THREADS) rs_pass_kernel(RsPassArgs a) {
+    __shared__ uint32_t wave_hist[RS_WAVES][RS_RADIX];
+    __shared__ uint32_t digit_base[RS_RADIX];
+    __shared__ int64_t gbase[RS_RADIX];                  // global position of LDS slot 0 for each digit (may be negative)
+    __shared__ uint32_t skeys[RS_TILE];
+    __shared__ uint32_t svals[RS_TILE];
+    __shared__ uint32_t wsum[RS_WAVES];
+    __shared__ uint32_t s_tile;
+
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    if (t == 0) s_tile = atomicAdd(a.ticket, 1u);
+    for (int i = t; i < RS_WAVES * RS_RADIX; i += RS_THREADS) (&wave_hist[0][0])[i] = 0;
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    const uint32_t tile_start = tile * (uint32_t)RS_TILE;
+    const uint32_t tile_n = min((uint32_t)RS_TILE, a.n - tile_start);
+
+    // ---- load (wave-striped: item i of lane l of wave w is element w*1024 + i*64 + l of the tile) and rank
+    uint32_t key[RS_ITEMS], val[RS_ITEMS], rank[RS_ITEMS];
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int i = 0; i < RS_ITEMS; ++i) {
+        const uint32_t e = (uint32_t)wv * (RS_ITEMS * WAVE) + (uint32_t)i * WAVE + lane;
+        const bool valid = e < tile_n;
+        key[i] = valid ? a.kin[tile_start + e] : 0xFFFFFFFFu;
+        val[i] = valid ? a.vin[tile_start + e] : 0u;
+    }
+#pragma unroll
+    for (int i = 0; i < RS_ITEMS; ++i) {
+        const uint32_t e = (uint32_t)wv * (RS_ITEMS * WAVE) + (uint32_t)i * WAVE + lane;
+        const bool valid = e < tile_n;
+        const uint32_t d = (key[i] >> a.shift) & 0xFFu;
+        unsigned long long peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const bool bit = (d >> b) & 1u;
+            const unsigned long long bm = __ballot(valid && bit);
+            peers &= bit ? bm : ~bm;
+        }
+        rank[i] = 0;
+        if (valid) {
+            const uint32_t prev = wave_hist[wv][d];                     // every peer reads the same counter ...
+            rank[i] = prev + (uint32_t)__popcll(peers & lt_mask);
+            if ((peers & lt_mask) == 0ull) wave_hist[wv][d] = prev + (uint32_t)__popcll(peers);   // ... the first peer bumps it
+        }
+    }
+    __syncthreads();
+
+    // ---- thread d owns digit d: per-wave exclusive prefixes, tile total, position of the digit inside the tile
+    uint32_t total;
+    {
+        uint32_t run = 0;
+#pragma unroll
+        for (int w = 0; w < RS_WAVES; ++w) {
+            const uint32_t c = wave_hist[w][t];
+            wave_hist[w][t] = run;
+            run += c;
+        }
+        total = run;
+    }
+    uint32_t incl = total;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t u = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += u;
+    }
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    uint32_t wadd = 0;
+    for (int w = 0; w < wv; ++w) wadd += wsum[w];
+    const uint32_t dbase = wadd + incl - total;
+    digit_base[t] = dbase;
+
+    // ---- publish, look back, publish (one digit per thread)
+    uint64_t* my = a.status + (size_t)tile * RS_RADIX + t;
+    uint64_t prefix = 0;
+    if (tile == 0) {
+        __hip_atomic_store(my, RS_FLAG_GLOBAL | (uint64_t)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        __hip_atomic_store(my, RS_FLAG_LOCAL | (uint64_t)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int64_t j = (int64_t)tile - 1; j >= 0; --j) {
+            const uint64_t* p = a.status + (size_t)j * RS_RADIX + t;
+            uint64_t w = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            uint32_t spins = 0;
+            while ((w >> 62) == 0ull) {
+                if (++spins > RS_SPIN_LIMIT) {
+                    atomicExch(a.error, 1u);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+                w = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            prefix += w & RS_COUNT_MASK;
+            if ((w >> 62) != 1ull) break;                 // GLOBAL (or a timed-out spin): stop
+        }
+        __hip_atomic_store(my, RS_FLAG_GLOBAL | (prefix + (uint64_t)total), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    }
+    gbase[t] = (int64_t)a.base[t] + (int64_t)prefix - (int64_t)dbase;
+    __syncthreads();
+
+    // ---- lay the tile out digit by digit in LDS (stable), then stream each run to its final place
+#pragma unroll
+    for (int i = 0; i < RS_ITEMS; ++i) {
+        const uint32_t e = (uint32_t)wv * (RS_ITEMS * WAVE) + (uint32_t)i * WAVE + lane;
+        if (e < tile_n) {
+            const uint32_t d = (key[i] >> a.shift) & 0xFFu;
+            const uint32_t pos = digit_base[d] + wave_hist[wv][d] + rank[i];
+            skeys[pos] = key[i];
+            svals[pos] = val[i];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < RS_ITEMS; ++i) {
+        const uint32_t p = (uint32_t)i * RS_THREADS + t;
+        if (p < tile_n) {
+            const uint32_t k = skeys[p];
+            const int64_t g = gbase[(k >> a.shift) & 0xFFu] + (int64_t)p;
+            a.kout[g] = k;
+            a.vout[g] = svals[p];
+        }
+    }
+}
+
+// Sorts n pairs on key bits [0, bits).  `ka`/`va` hold the input; the passes ping-pong between
+// (ka, va) and (kb, vb).  The sorted pairs end in (kb, vb) when the number of passes is odd and in
+// (ka, va) when it is even (radix_result_in_b tells which).
+bool radix_result_in_b(int bits) { return (rs_passes(bits) & 1) != 0; }
+
+int radix_sort_pairs(uint32_t* ka, uint32_t* va, uint32_t* kb, uint32_t* vb, uint64_t n, int bits, void* temp,
+                     hipStream_t s) {
+    if (n == 0) return 0;
+    if (n >= (1ull << 32)) { set_error("radix sort: more than 2^32-1 pairs"); return 1; }
+    const int npasses = rs_passes(bits);
+    if (npasses > RS_MAX_PASSES) { set_error("radix sort: more than 32 key bits"); return 1; }
+    const RsTemp t = rs_carve(temp, n, bits);
+    MGS_HIP(hipMemsetAsync(t.hist, 0, t.zero_bytes, s));
+    const uint32_t tiles = rs_tiles(n);
+    const uint32_t hist_blocks = min(tiles, 256u);
+    hipLaunchKernelGGL(rs_hist_kernel, dim3(hist_blocks), dim3(RS_THREADS), 0, s, ka, (uint32_t)n, npasses, t.hist);
+    hipLaunchKernelGGL(rs_scan_kernel, dim3(npasses), dim3(RS_RADIX), 0, s, t.hist, t.base);
+    uint32_t *kin = ka, *vin = va, *kout = kb, *vout = vb;
+    for (int p = 0; p < npasses; ++p) {
+        RsPassArgs a;
+        a.kin = kin; a.kout = kout; a.vin = vin; a.vout = vout;
+        a.n = (uint32_t)n; a.shift = 8 * p;
+        a.base = t.base + p * RS_RADIX;
+        a.status = t.status + (size_t)p * tiles * RS_RADIX;
+        a.ticket = t.tickets + p;
+        a.error = t.error;
+        hipLaunchKernelGGL(rs_pass_kernel, dim3(tiles), dim3(RS_THREADS), 0, s, a);
+        uint32_t* tk = kin; kin = kout; kout = tk;
+        uint32_t* tv = vin; vin = vout; vout = tv;
+    }
+    MGS_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace mgs

@@ -59,10 +59,17 @@ def forward_tables(rs, means3D, opacities, colors_precomp=None, shs=None, scales
     n_contrib = view(img, _au(HW * 4), HW * 4, torch.int32).reshape(H, W)
     ranges = view(img, 2 * _au(HW * 4), ntiles * 8, torch.int32).reshape(ntiles, 2)
     r = max(R, 1)
-    keys_sorted = view(binning, _au(r * 8), R * 8, torch.int64)
-    point_list = view(binning, 2 * _au(r * 8) + _au(r * 4), R * 4, torch.int32)
+    # binning scratch: keys_a, keys_b, vals_a, vals_b; an LSD pass per 8 key bits ping-pongs a -> b -> a ...
+    tile_bits = max(1, (ntiles - 1).bit_length())
+    in_b = ((tile_bits + 7) // 8) % 2 == 1
+    tile_sorted = view(binning, _au(r * 4) if in_b else 0, R * 4, torch.int32)      # tile id per instance, grouped
+    point_list = view(binning, (3 if in_b else 2) * _au(r * 4), R * 4, torch.int32)
     rec = view(geom, 0, P * 64, torch.float32).reshape(P, 16)
-    tiles_touched = view(geom, _au(P * 64), P * 4, torch.int32)
+    o = _au(P * 64)
+    tiles_touched = view(geom, o, P * 4, torch.int32)
+    # geometry scratch after tiles_touched: depth_key, depth_alt, iota, iota_alt (4 passes: result back in iota)
+    perm = view(geom, o + 3 * _au(P * 4), P * 4, torch.int32)
+    depth_key = rec[:, 11].contiguous().view(torch.int32)          # float32 bits of the view-space depth
     return dict(color=color, depth=depth, opacity=opacity, radii=radii, n_touched=n_touched, num_rendered=R,
-                final_T=final_T, n_contrib=n_contrib, ranges=ranges, keys_sorted=keys_sorted,
-                point_list=point_list, rec=rec, tiles_touched=tiles_touched)
+                final_T=final_T, n_contrib=n_contrib, ranges=ranges, tile_sorted=tile_sorted,
+                point_list=point_list, rec=rec, tiles_touched=tiles_touched, depth_key=depth_key, perm=perm)

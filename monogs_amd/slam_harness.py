@@ -175,7 +175,8 @@ def make_sequence(n_frames: int, intrinsics="fr3_office", n_gaussians=60000, see
 
 
 def run_slam(n_frames=12, intrinsics="fr3_office", tracking_itr_num=100, mapping_itr_num=150, window_size=8,
-             kf_interval=4, init_itr_num=300, n_gaussians=60000, device="cuda:0", log=None):
+             kf_interval=4, init_itr_num=300, n_gaussians=60000, device="cuda:0", log=None,
+             init_downsample=8, kf_downsample=16, point_size=1.0):
     """Returns a dict with tracking / mapping FPS, iterations and the trajectory error."""
     frames, intr = make_sequence(n_frames, intrinsics, n_gaussians, device=device)
     bg = torch.zeros(3, device=device)
@@ -214,7 +215,7 @@ def run_slam(n_frames=12, intrinsics="fr3_office", tracking_itr_num=100, mapping
         if i == 0:
             vp.update_RT(vp.R_gt, vp.T_gt)
             sync(); t0 = time.perf_counter()
-            gmap.extend_from_frame(vp, intr, downsample=32, init=True)
+            gmap.extend_from_frame(vp, intr, downsample=init_downsample, init=True, point_size=point_size)
             window.append(vp)
             map_window(init_itr_num, init=True)
             sync(); stats["map_s"] += time.perf_counter() - t0
@@ -247,7 +248,7 @@ def run_slam(n_frames=12, intrinsics="fr3_office", tracking_itr_num=100, mapping
             sync(); t0 = time.perf_counter()
             with torch.no_grad():
                 pkg = _render(vp, intr, gmap, bg)
-            gmap.extend_from_frame(vp, intr, downsample=64, render_opacity=pkg["opacity"])
+            gmap.extend_from_frame(vp, intr, downsample=kf_downsample, render_opacity=pkg["opacity"], point_size=point_size)
             window.append(vp)
             if len(window) > window_size:
                 window.pop(1)
@@ -255,7 +256,11 @@ def run_slam(n_frames=12, intrinsics="fr3_office", tracking_itr_num=100, mapping
             sync(); stats["map_s"] += time.perf_counter() - t0
             stats["keyframes"] += 1
         if log:
-            log(f"frame {i}: P={gmap.get_xyz.shape[0]} track_iters={stats['track_iters']} kf={stats['keyframes']}")
+            e = (-(vp.R.t() @ vp.T) + (vp.R_gt.t() @ vp.T_gt)).norm().item()
+            with torch.no_grad():
+                cov = (_render(vp, intr, gmap, bg)["opacity"] > 0.99).float().mean().item()
+            log(f"frame {i}: P={gmap.get_xyz.shape[0]} track_iters={stats['track_iters']} kf={stats['keyframes']} "
+                f"pos_err={e:.4f} m  opaque>0.99={cov:.2f} last_loss={float(loss):.5f}")
 
     err = torch.stack([(-(f.R.t() @ f.T) + (f.R_gt.t() @ f.T_gt)).norm() for f in frames[1:]])
     out = dict(stats)

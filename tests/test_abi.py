@@ -44,7 +44,7 @@ def test_scratch_size_functions_are_pure(native_lib):
 def test_struct_layout_matches_header():
     from monogs_amd import _lib
     assert ctypes.sizeof(_lib.MgsCamera) == 8 * 4 + 5 * 8
-    assert ctypes.sizeof(_lib.MgsTiming) == 8 * 4
+    assert ctypes.sizeof(_lib.MgsTiming) == 9 * 4
 
 
 def test_code_object_targets_gfx950(native_lib):

@@ -77,8 +77,11 @@ def test_forward_tables_bit_exact(native_lib, P, intr, seed, aniso):
     assert torch.equal(t["tiles_touched"].cpu().long(), o.aux["geom"]["tiles_touched"])
     assert torch.equal(t["ranges"].cpu().long(), o.aux["ranges"])
     assert torch.equal(t["point_list"].cpu().long(), o.aux["point_list"])
-    keys = torch.from_numpy(o.aux["keys"].astype("int64"))
-    assert torch.equal(t["keys_sorted"].cpu(), keys)
+    keys = torch.from_numpy(o.aux["keys"].astype("int64"))          # tile << 32 | depth bits, sorted
+    assert torch.equal(t["tile_sorted"].cpu().long(), keys >> 32)
+    # the depth bits of every instance, read back through the blend order, reproduce the oracle's keys
+    dk = t["depth_key"].cpu().long() & 0xFFFFFFFF
+    assert torch.equal(dk[t["point_list"].cpu().long()], keys & 0xFFFFFFFF)
     amb = o.aux["ambiguous"]
     ok = ~amb
     err = (t["color"].cpu() - o.color).abs().amax(0)

@@ -137,6 +137,27 @@ size_t mgs_knn_scratch_bytes(int32_t P);
 int mgs_dist2_knn(int32_t P, const float* points /* [P,3] */, float* out /* [P] */,
                   void* scratch, void* stream);
 
+/* ---- Fused SLAM losses (caller-side widening) --------------------------------
+ * Forward value + analytic gradients of get_loss_mapping (/root/reference/utils/slam_utils.py:101-146,
+ * tracking = 0) and get_loss_tracking (:58-98, tracking = 1).  render[3,H,W], depth[1,H,W], opacity[1,H,W]
+ * (tracking only), gt_rgb[3,H,W], gt_depth[H,W]; mask / grad_mask are [H,W] bytes (0 / non-zero; mask may be
+ * NULL = all ones); exposure_a / exposure_b are device scalars (ignored when init != 0: rgb = render).
+ * mgs_loss_forward writes the scalar loss to loss_out [device] and keeps its sums in `scratch`
+ * (mgs_loss_scratch_bytes); mgs_loss_backward turns them into d_render[3,H,W], d_depth[1,H,W] and
+ * d_exposure[2] = (dL/da, dL/db; may be NULL), all scaled by the device scalar grad_out (NULL = 1).
+ * The opacity image gets no gradient (the rasteriser ignores dL/dopacity). */
+size_t mgs_loss_scratch_bytes(void);
+int mgs_loss_forward(int32_t width, int32_t height, int32_t tracking, int32_t init, float lambda_rgb,
+                     const float* render, const float* depth, const float* opacity, const float* gt_rgb,
+                     const float* gt_depth, const uint8_t* mask, const uint8_t* grad_mask,
+                     const float* exposure_a, const float* exposure_b, float* scratch, float* loss_out,
+                     void* stream);
+int mgs_loss_backward(int32_t width, int32_t height, int32_t tracking, int32_t init, float lambda_rgb,
+                      const float* render, const float* depth, const float* opacity, const float* gt_rgb,
+                      const float* gt_depth, const uint8_t* mask, const uint8_t* grad_mask,
+                      const float* exposure_a, const float* exposure_b, const float* scratch,
+                      const float* grad_out, float* d_render, float* d_depth, float* d_exposure, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

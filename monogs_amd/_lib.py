@@ -51,6 +51,10 @@ SIGNATURES = {
                      + [C.c_void_p] * 4 + [C.c_void_p] * 2 + [C.c_void_p] * 9
                      + [C.c_void_p, C.POINTER(MgsTiming), C.c_void_p]),
     "mgs_mark_visible": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mgs_loss_scratch_bytes": (C.c_size_t, []),
+    "mgs_loss_forward": (C.c_int, [C.c_int32] * 4 + [C.c_float] + [C.c_void_p] * 9 + [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mgs_loss_backward": (C.c_int, [C.c_int32] * 4 + [C.c_float] + [C.c_void_p] * 9
+                          + [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mgs_knn_scratch_bytes": (C.c_size_t, [C.c_int32]),
     "mgs_dist2_knn": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
 }

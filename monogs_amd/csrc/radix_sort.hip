@@ -31,7 +31,8 @@ constexpr int RS_MAX_PASSES = 4;
 constexpr uint64_t RS_FLAG_LOCAL = 1ull << 62;     // count of this tile only
 constexpr uint64_t RS_FLAG_GLOBAL = 2ull << 62;    // inclusive count over tiles 0..this
 constexpr uint64_t RS_COUNT_MASK = (1ull << 62) - 1;
-constexpr uint32_t RS_SPIN_LIMIT = 1u << 24;
+constexpr uint32_t RS_SPIN_LIMIT = 1u << 22;
+constexpr int RS_WINDOW = 16;                     // predecessor status words fetched per look-back step
 
 static inline int rs_passes(int bits) { return (bits + 7) / 8; }
 static inline uint32_t rs_tiles(uint64_t n) { return (uint32_t)((n + RS_TILE - 1) / RS_TILE); }
@@ -68,18 +69,23 @@ size_t radix_temp_bytes(uint64_t n, int bits) {
 // ------------------------------------------------------------------------------------------------
 struct RsShifts { int npasses; };
 
+// Digit counts of every pass in one read of the keys.  Each wave keeps a private copy of the
+// histograms in LDS (4x fewer same-address LDS atomics; the tile-id digits are low-entropy).
 __global__ void __launch_bounds__(RS_THREADS) rs_hist_kernel(const uint32_t* __restrict__ keys, uint32_t n, int npasses,
                                                              uint32_t* __restrict__ hist) {
-    __shared__ uint32_t lh[RS_MAX_PASSES][RS_RADIX];
-    for (int i = threadIdx.x; i < RS_MAX_PASSES * RS_RADIX; i += RS_THREADS) (&lh[0][0])[i] = 0;
+    __shared__ uint32_t lh[RS_WAVES][RS_MAX_PASSES][RS_RADIX];
+    for (int i = threadIdx.x; i < RS_WAVES * RS_MAX_PASSES * RS_RADIX; i += RS_THREADS) (&lh[0][0][0])[i] = 0;
     __syncthreads();
+    const int wv = threadIdx.x >> 6;
     for (uint32_t i = blockIdx.x * RS_THREADS + threadIdx.x; i < n; i += gridDim.x * RS_THREADS) {
         const uint32_t k = keys[i];
-        for (int p = 0; p < npasses; ++p) atomicAdd(&lh[p][(k >> (8 * p)) & 0xFF], 1u);
+        for (int p = 0; p < npasses; ++p) atomicAdd(&lh[wv][p][(k >> (8 * p)) & 0xFF], 1u);
     }
     __syncthreads();
     for (int i = threadIdx.x; i < npasses * RS_RADIX; i += RS_THREADS) {
-        const uint32_t c = (&lh[0][0])[i];
+        uint32_t c = 0;
+#pragma unroll
+        for (int w = 0; w < RS_WAVES; ++w) c += (&lh[w][0][0])[i];
         if (c) atomicAdd(hist + i, c);
     }
 }
@@ -195,20 +201,41 @@ __global__ void __launch_bounds__(RS_THREADS) rs_pass_kernel(RsPassArgs a) {
         __hip_atomic_store(my, RS_FLAG_GLOBAL | (uint64_t)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
         __hip_atomic_store(my, RS_FLAG_LOCAL | (uint64_t)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        for (int64_t j = (int64_t)tile - 1; j >= 0; --j) {
-            const uint64_t* p = a.status + (size_t)j * RS_RADIX + t;
-            uint64_t w = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            uint32_t spins = 0;
-            while ((w >> 62) == 0ull) {
+        // Batched look-back: RS_WINDOW predecessor words are requested at once (independent loads, one
+        // memory latency), then consumed nearest-first.  With every resident tile starting together the
+        // serial walk costs ~sqrt(2*tiles) dependent round trips; the window divides that by RS_WINDOW.
+        int64_t j = (int64_t)tile - 1;
+        bool found = false;
+        uint32_t spins = 0;
+        while (!found) {
+            uint64_t w[RS_WINDOW];
+#pragma unroll
+            for (int q = 0; q < RS_WINDOW; ++q) {
+                const int64_t jj = j - q;
+                w[q] = jj >= 0 ? __hip_atomic_load(a.status + (size_t)jj * RS_RADIX + t, __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT)
+                               : RS_FLAG_GLOBAL;              // virtual tile -1: inclusive count 0
+            }
+            int used = 0;
+#pragma unroll
+            for (int q = 0; q < RS_WINDOW; ++q) {
+                if (!found && used == q) {
+                    const uint64_t f = w[q] >> 62;
+                    if (f != 0ull) {
+                        prefix += w[q] & RS_COUNT_MASK;
+                        ++used;
+                        found = (f != 1ull);
+                    }
+                }
+            }
+            j -= used;
+            if (!found && used == 0) {                       // nearest predecessor not published yet
                 if (++spins > RS_SPIN_LIMIT) {
                     atomicExch(a.error, 1u);
                     break;
                 }
                 __builtin_amdgcn_s_sleep(1);
-                w = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            prefix += w & RS_COUNT_MASK;
-            if ((w >> 62) != 1ull) break;                 // GLOBAL (or a timed-out spin): stop
         }
         __hip_atomic_store(my, RS_FLAG_GLOBAL | (prefix + (uint64_t)total), __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
@@ -254,7 +281,7 @@ int radix_sort_pairs(uint32_t* ka, uint32_t* va, uint32_t* kb, uint32_t* vb, uin
     const RsTemp t = rs_carve(temp, n, bits);
     MGS_HIP(hipMemsetAsync(t.hist, 0, t.zero_bytes, s));
     const uint32_t tiles = rs_tiles(n);
-    const uint32_t hist_blocks = min(tiles, 256u);
+    const uint32_t hist_blocks = min(tiles, 1024u);
     hipLaunchKernelGGL(rs_hist_kernel, dim3(hist_blocks), dim3(RS_THREADS), 0, s, ka, (uint32_t)n, npasses, t.hist);
     hipLaunchKernelGGL(rs_scan_kernel, dim3(npasses), dim3(RS_RADIX), 0, s, t.hist, t.base);
     uint32_t *kin = ka, *vin = va, *kout = kb, *vout = vb;

@@ -1,0 +1,89 @@
+"""Fused ``get_loss_mapping`` / ``get_loss_tracking`` (HIP, forward value + analytic gradients).
+
+Same signatures and values as /root/reference/utils/slam_utils.py:58-146 (mirrored in plain PyTorch in
+``monogs_amd.slam_losses`` and checked there against the reference's own outputs); one reduction kernel
+per forward and one elementwise kernel per backward instead of ~60 small kernels and two host syncs.
+Differences, both invisible to the rasteriser: the opacity image receives no gradient from the tracking
+loss (the rasteriser ignores dL/dopacity anyway), and ``invert_depth`` is not supported (always False in
+the reference's callers).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from .rasterizer import _f32, _stream
+
+
+def _u8(t):
+    if t is None:
+        return None
+    if t.dtype == torch.bool:
+        return t.contiguous().view(torch.uint8)
+    return (t != 0).to(torch.uint8).contiguous()
+
+
+class _FusedLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, render, depth, opacity, exp_a, exp_b, gt_rgb, gt_depth, mask, grad_mask, tracking, init, lam):
+        lib = _lib.load()
+        render = _f32(render.detach(), "render_image")
+        depth = _f32(depth.detach(), "render_depth")
+        H, W = render.shape[-2:]
+        dev = render.device
+        opac = _f32(opacity.detach(), "render_opacity") if opacity is not None else None
+        gt_rgb, gt_depth = _f32(gt_rgb, "viewpoint.rgb"), _f32(gt_depth, "viewpoint.depth")
+        a = _f32(exp_a.detach(), "exposure_a") if exp_a is not None else None
+        b = _f32(exp_b.detach(), "exposure_b") if exp_b is not None else None
+        p = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+        with torch.cuda.device(dev):
+            scratch = torch.empty(lib.mgs_loss_scratch_bytes() // 4, dtype=torch.float32, device=dev)
+            loss = torch.empty((), dtype=torch.float32, device=dev)
+            _lib.check(lib.mgs_loss_forward(W, H, int(tracking), int(init), float(lam), p(render), p(depth), p(opac),
+                                            p(gt_rgb), p(gt_depth), p(mask), p(grad_mask), p(a), p(b),
+                                            p(scratch), p(loss), _stream()), "mgs_loss_forward")
+        ctx.cfg = (W, H, int(tracking), int(init), float(lam))
+        ctx.has_mask, ctx.has_gm, ctx.has_op, ctx.has_ab = mask is not None, grad_mask is not None, opac is not None, a is not None
+        dummy = torch.empty(0, device=dev)
+        ctx.save_for_backward(render, depth, opac if opac is not None else dummy, gt_rgb, gt_depth,
+                              mask if mask is not None else dummy, grad_mask if grad_mask is not None else dummy,
+                              a if a is not None else dummy, b if b is not None else dummy, scratch)
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        lib = _lib.load()
+        render, depth, opac, gt_rgb, gt_depth, mask, gm, a, b, scratch = ctx.saved_tensors
+        W, H, tracking, init, lam = ctx.cfg
+        dev = render.device
+        p = lambda t, ok=True: t.data_ptr() if ok else None  # noqa: E731
+        with torch.cuda.device(dev):
+            go = _f32(grad_out.reshape(1), "grad_output")
+            d_render = torch.empty_like(render)
+            d_depth = torch.empty_like(depth)
+            want_ab = ctx.has_ab and not init and (ctx.needs_input_grad[3] or ctx.needs_input_grad[4])
+            d_ab = torch.empty(2, dtype=torch.float32, device=dev) if want_ab else None
+            _lib.check(lib.mgs_loss_backward(W, H, tracking, init, lam, p(render), p(depth), p(opac, ctx.has_op),
+                                             p(gt_rgb), p(gt_depth), p(mask, ctx.has_mask), p(gm, ctx.has_gm),
+                                             p(a, ctx.has_ab), p(b, ctx.has_ab), p(scratch), p(go), p(d_render),
+                                             p(d_depth), d_ab.data_ptr() if d_ab is not None else None, _stream()),
+                       "mgs_loss_backward")
+        d_a = d_ab[0:1].clone() if d_ab is not None else None
+        d_b = d_ab[1:2].clone() if d_ab is not None else None
+        return (d_render, d_depth, None, d_a, d_b, None, None, None, None, None, None, None)
+
+
+def get_loss_mapping(render_image, render_depth, viewpoint, init=False, invert_depth=False, lambda_depth=0.9):
+    if invert_depth:
+        raise NotImplementedError("invert_depth is not fused; use monogs_amd.slam_losses.get_loss_mapping")
+    return _FusedLoss.apply(render_image, render_depth, None, viewpoint.exposure_a, viewpoint.exposure_b,
+                            viewpoint.rgb, viewpoint.depth, _u8(viewpoint.mask), None, False, bool(init),
+                            float(lambda_depth))
+
+
+def get_loss_tracking(render_image, render_depth, render_opacity, viewpoint, invert_depth=False, lambda_depth=0.9):
+    if invert_depth:
+        raise NotImplementedError("invert_depth is not fused; use monogs_amd.slam_losses.get_loss_tracking")
+    return _FusedLoss.apply(render_image, render_depth, render_opacity, viewpoint.exposure_a, viewpoint.exposure_b,
+                            viewpoint.rgb, viewpoint.depth, _u8(viewpoint.mask), _u8(viewpoint.grad_mask), True,
+                            False, 0.9)

@@ -17,6 +17,14 @@ import torch
 from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
 
 
+def _camera_center(world_view: torch.Tensor) -> torch.Tensor:
+    """Camera centre -R^T t read off the transposed world->view matrix.  Same value as the reference's
+    ``camera_center`` property (``world_view_transform.inverse()[3, :3]``,
+    /root/reference/utils/camera_utils.py:176-178) without a 4x4 LU inverse per render; it only feeds the
+    SH view direction, which this fork never uses (colours are precomputed)."""
+    return -(world_view[:3, :3] @ world_view[3, :3])
+
+
 def render(viewpoint_camera, cam_intrinsics, means, rotations, scales, opacity, features, bg_color,
            scaling_modifier=1.0, override_color=None, mask=None):
     if means.shape[0] == 0:
@@ -38,7 +46,7 @@ def render(viewpoint_camera, cam_intrinsics, means, rotations, scales, opacity, 
         image_height=int(cam_intrinsics.height), image_width=int(cam_intrinsics.width),
         tanfovx=tanfovx, tanfovy=tanfovy, bg=bg_color, scale_modifier=scaling_modifier,
         viewmatrix=world_view, projmatrix=full_proj, projmatrix_raw=projection_matrix,
-        sh_degree=0, campos=viewpoint_camera.camera_center, prefiltered=False, debug=False)
+        sh_degree=0, campos=_camera_center(world_view), prefiltered=False, debug=False)
 
     if scales.shape[-1] == 1:          # isotropic map
         scales = scales.repeat(1, 3)

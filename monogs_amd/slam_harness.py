@@ -27,7 +27,7 @@ import torch
 from . import camera as cam
 from .knn import distCUDA2
 from .renderer import render
-from .slam_losses import get_loss_mapping, get_loss_tracking
+from . import fused_losses, slam_losses
 from .synthetic import make_scene
 
 
@@ -176,9 +176,11 @@ def make_sequence(n_frames: int, intrinsics="fr3_office", n_gaussians=60000, see
 
 def run_slam(n_frames=12, intrinsics="fr3_office", tracking_itr_num=100, mapping_itr_num=150, window_size=8,
              kf_interval=4, init_itr_num=300, n_gaussians=60000, device="cuda:0", log=None,
-             init_downsample=8, kf_downsample=16, point_size=1.0):
+             init_downsample=8, kf_downsample=16, point_size=1.0, fused_losses_on=True):
     """Returns a dict with tracking / mapping FPS, iterations and the trajectory error."""
     frames, intr = make_sequence(n_frames, intrinsics, n_gaussians, device=device)
+    L = fused_losses if fused_losses_on else slam_losses
+    get_loss_mapping, get_loss_tracking = L.get_loss_mapping, L.get_loss_tracking
     bg = torch.zeros(3, device=device)
     gmap = GaussianMap(device)
     window: List[Viewpoint] = []
@@ -270,6 +272,7 @@ def run_slam(n_frames=12, intrinsics="fr3_office", tracking_itr_num=100, mapping
                mapping_iters_per_s=stats["map_iters"] / max(stats["map_s"], 1e-9),
                mapping_kf_per_s=stats["keyframes"] / max(stats["map_s"], 1e-9),
                ate_rmse_m=float(torch.sqrt((err ** 2).mean())),
+               fused_losses=bool(fused_losses_on),
                config=dict(tracking_itr_num=tracking_itr_num, mapping_itr_num=mapping_itr_num,
                            window_size=window_size, kf_interval=kf_interval, init_itr_num=init_itr_num))
     return out

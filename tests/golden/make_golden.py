@@ -7,7 +7,7 @@
 Outputs (data only -- inputs and the reference's outputs):
   camera_pose.npz : getProjectionMatrix / getWorld2View / CameraIntrinsics.FoV / SE3_exp / update_pose
   sh_eval.npz     : eval_sh for degrees 0..3 on seeded inputs
-  losses.npz      : get_loss_mapping value and autograd gradients w.r.t. (render, depth) on seeded images
+  losses.npz      : get_loss_mapping / get_loss_tracking values and autograd gradients on seeded images
 """
 import math
 import os
@@ -24,7 +24,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 from gaussian_splatting.utils.graphics_utils import getProjectionMatrix, getWorld2View  # noqa: E402
 from gaussian_splatting.utils.sh_utils import eval_sh  # noqa: E402
 from utils.pose_utils import SE3_exp, SO3_exp, V, update_pose  # noqa: E402
-from utils.slam_utils import get_loss_mapping  # noqa: E402
+from utils.slam_utils import get_loss_mapping, get_loss_tracking  # noqa: E402
 
 INTR = {
     "fr3_office": dict(fx=535.4, fy=539.2, cx=320.1, cy=247.6, W=640, H=480),
@@ -118,6 +118,16 @@ def losses():
         out[f"loss_{tag}"] = np.array([loss.item()], dtype=np.float64)
         out[f"grad_render_{tag}"] = gr.numpy()
         out[f"grad_depth_{tag}"] = gd.numpy()
+    # tracking loss (needs grad_mask and the rendered opacity; > 0.99 on part of the image)
+    vp.grad_mask = torch.rand(H, W, generator=g) > 0.4
+    opacity = torch.rand(1, H, W, generator=g)
+    opacity[torch.rand(1, H, W, generator=g) < 0.6] = 0.995
+    opacity = opacity.requires_grad_(True)
+    out["grad_mask"], out["opacity"] = vp.grad_mask.numpy(), opacity.detach().numpy()
+    loss = get_loss_tracking(render, depth, opacity, vp)
+    gr, gd, go = torch.autograd.grad(loss, [render, depth, opacity])
+    out["loss_track"] = np.array([loss.item()], dtype=np.float64)
+    out["grad_render_track"], out["grad_depth_track"], out["grad_opacity_track"] = gr.numpy(), gd.numpy(), go.numpy()
     np.savez_compressed(os.path.join(HERE, "losses.npz"), **out)
 
 

@@ -158,6 +158,17 @@ int mgs_loss_backward(int32_t width, int32_t height, int32_t tracking, int32_t i
                       const float* exposure_a, const float* exposure_b, const float* scratch,
                       const float* grad_out, float* d_render, float* d_depth, float* d_exposure, void* stream);
 
+/* ---- Fused pose update (caller-side widening) -------------------------------
+ * torch.optim.Adam.step() on (cam_rot_delta lr_rot, cam_trans_delta lr_trans, exposure_a/b lr_exposure)
+ * followed by update_pose (/root/reference/utils/pose_utils.py:76-93): T_cw <- exp([rho; theta]^) T_cw,
+ * deltas reset to zero.  R[3,3] (row-major), T[3], the parameters and the Adam moments adam_m[8], adam_v[8]
+ * (order rot(3), trans(3), a, b) are device tensors updated in place; `step` is the 1-based Adam step;
+ * out[2] = {converged (|tau| < converged_threshold ? 1 : 0), |tau|}.  exposure pointers / any gradient may be NULL. */
+int mgs_pose_step(float* R, float* T, float* rot_delta, float* trans_delta, float* exposure_a, float* exposure_b,
+                  const float* grad_rot, const float* grad_trans, const float* grad_a, const float* grad_b,
+                  float* adam_m, float* adam_v, int32_t step, float lr_rot, float lr_trans, float lr_exposure,
+                  float beta1, float beta2, float eps, float converged_threshold, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,109 @@
+// Fused pose update of the tracking / mapping loops: Adam step on (cam_rot_delta, cam_trans_delta,
+// exposure_a, exposure_b) followed by the SE(3) retraction  T_cw <- exp([rho; theta]^) T_cw  and the reset
+// of the deltas -- what the reference does with torch.optim.Adam.step() plus utils/pose_utils.py:76-93
+// (`update_pose`) in ~60 tiny launches and one host sync per iteration.  One single-wave kernel here.
+// Caller-side widening (optimiser step next to the rasteriser backward).
+#include "common.h"
+
+namespace mgs {
+
+struct PoseStepArgs {
+    float* R;             // [3,3] row-major world->camera rotation, updated in place
+    float* T;             // [3]
+    float* rot_delta;     // [3] parameter (zero on entry, zero on exit)
+    float* trans_delta;   // [3]
+    float* exp_a;         // [1] parameter, updated in place (may be NULL)
+    float* exp_b;         // [1]
+    const float* g_rot;   // gradients (NULL = zero)
+    const float* g_trans;
+    const float* g_a;
+    const float* g_b;
+    float* m;             // [8] Adam first moments: rot(3) trans(3) a b
+    float* v;             // [8] Adam second moments
+    float* out;           // [2] {converged (0/1), |tau|}
+    float lr_rot, lr_trans, lr_exp, beta1, beta2, eps, converged_threshold;
+    int step;             // 1-based Adam step count of this update
+};
+
+__device__ __forceinline__ void mat3mul(const float* A, const float* B, float* C) {
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) C[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+}
+
+__global__ void pose_step_kernel(PoseStepArgs a) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    // ---- Adam (torch.optim.Adam defaults: no weight decay, no amsgrad), one scalar at a time
+    const float bc1 = 1.f - powf(a.beta1, (float)a.step), bc2 = 1.f - powf(a.beta2, (float)a.step);
+    float p[8], g[8];
+    for (int i = 0; i < 3; ++i) {
+        p[i] = a.rot_delta[i];     g[i] = a.g_rot ? a.g_rot[i] : 0.f;
+        p[3 + i] = a.trans_delta[i]; g[3 + i] = a.g_trans ? a.g_trans[i] : 0.f;
+    }
+    p[6] = a.exp_a ? a.exp_a[0] : 0.f; g[6] = a.g_a ? a.g_a[0] : 0.f;
+    p[7] = a.exp_b ? a.exp_b[0] : 0.f; g[7] = a.g_b ? a.g_b[0] : 0.f;
+    for (int i = 0; i < 8; ++i) {
+        const float lr = i < 3 ? a.lr_rot : (i < 6 ? a.lr_trans : a.lr_exp);
+        const float m = a.beta1 * a.m[i] + (1.f - a.beta1) * g[i];
+        const float v = a.beta2 * a.v[i] + (1.f - a.beta2) * g[i] * g[i];
+        a.m[i] = m; a.v[i] = v;
+        const float denom = sqrtf(v) / sqrtf(bc2) + a.eps;
+        p[i] = p[i] - (lr / bc1) * (m / denom);
+    }
+    if (a.exp_a) a.exp_a[0] = p[6];
+    if (a.exp_b) a.exp_b[0] = p[7];
+    // ---- tau = [rho; theta];  T <- exp(tau^) T   (/root/reference/utils/pose_utils.py:25-93)
+    const float th[3] = {p[0], p[1], p[2]}, rho[3] = {p[3], p[4], p[5]};
+    const float W[9] = {0.f, -th[2], th[1], th[2], 0.f, -th[0], -th[1], th[0], 0.f};
+    float W2[9];
+    mat3mul(W, W, W2);
+    const float angle = sqrtf(th[0] * th[0] + th[1] * th[1] + th[2] * th[2]);
+    float ca, cb, va, vb;   // R = I + ca W + cb W2 ; V = I + va W + vb W2
+    if (angle < 1e-5f) {
+        ca = 1.f; cb = 0.5f; va = 0.5f; vb = 1.f / 6.f;
+    } else {
+        const float s = sinf(angle), c = cosf(angle), a2 = angle * angle;
+        ca = s / angle; cb = (1.f - c) / a2; va = (1.f - c) / a2; vb = (angle - s) / (a2 * angle);
+    }
+    float dR[9], V[9];
+    for (int i = 0; i < 9; ++i) {
+        const float eye = (i % 4 == 0) ? 1.f : 0.f;
+        dR[i] = eye + ca * W[i] + cb * W2[i];
+        V[i] = eye + va * W[i] + vb * W2[i];
+    }
+    float dt[3];
+    for (int i = 0; i < 3; ++i) dt[i] = V[3 * i] * rho[0] + V[3 * i + 1] * rho[1] + V[3 * i + 2] * rho[2];
+    float Rn[9], Ro[9], To[3];
+    for (int i = 0; i < 9; ++i) Ro[i] = a.R[i];
+    for (int i = 0; i < 3; ++i) To[i] = a.T[i];
+    mat3mul(dR, Ro, Rn);
+    for (int i = 0; i < 9; ++i) a.R[i] = Rn[i];
+    for (int i = 0; i < 3; ++i) a.T[i] = dR[3 * i] * To[0] + dR[3 * i + 1] * To[1] + dR[3 * i + 2] * To[2] + dt[i];
+    const float tn = sqrtf(rho[0] * rho[0] + rho[1] * rho[1] + rho[2] * rho[2] + angle * angle);
+    a.out[0] = tn < a.converged_threshold ? 1.f : 0.f;
+    a.out[1] = tn;
+    for (int i = 0; i < 3; ++i) { a.rot_delta[i] = 0.f; a.trans_delta[i] = 0.f; }
+}
+
+}  // namespace mgs
+
+using namespace mgs;
+
+extern "C" int mgs_pose_step(float* R, float* T, float* rot_delta, float* trans_delta, float* exposure_a,
+                             float* exposure_b, const float* grad_rot, const float* grad_trans, const float* grad_a,
+                             const float* grad_b, float* adam_m, float* adam_v, int32_t step, float lr_rot,
+                             float lr_trans, float lr_exposure, float beta1, float beta2, float eps,
+                             float converged_threshold, float* out, void* stream) {
+    if (!R || !T || !rot_delta || !trans_delta || !adam_m || !adam_v || !out) {
+        set_error("R, T, rot_delta, trans_delta, adam_m, adam_v, out must be non-NULL");
+        return 1;
+    }
+    if (step < 1) { set_error("step is 1-based"); return 1; }
+    PoseStepArgs a;
+    a.R = R; a.T = T; a.rot_delta = rot_delta; a.trans_delta = trans_delta; a.exp_a = exposure_a; a.exp_b = exposure_b;
+    a.g_rot = grad_rot; a.g_trans = grad_trans; a.g_a = grad_a; a.g_b = grad_b; a.m = adam_m; a.v = adam_v; a.out = out;
+    a.lr_rot = lr_rot; a.lr_trans = lr_trans; a.lr_exp = lr_exposure; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
+    a.converged_threshold = converged_threshold; a.step = step;
+    hipLaunchKernelGGL(pose_step_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a);
+    MGS_HIP(hipGetLastError());
+    return 0;
+}

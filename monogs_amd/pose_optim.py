@@ -1,0 +1,51 @@
+"""Fused pose optimiser step: Adam on the per-camera deltas / exposure + SE(3) retraction in one launch.
+
+Equivalent to the reference's per-iteration sequence
+    pose_optimizer.step(); converged = update_pose(viewpoint)
+(/root/reference/utils/slam_tracker.py:172-174, utils/slam_mapper.py:486-496, utils/pose_utils.py:76-93)
+with torch.optim.Adam defaults; checked against exactly that sequence in tests/test_gpu_pose.py.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from .rasterizer import _stream
+
+
+class PoseAdam:
+    def __init__(self, viewpoint, lr_rot=0.003, lr_trans=0.001, lr_exposure=0.01, betas=(0.9, 0.999), eps=1e-8):
+        self.vp = viewpoint
+        self.lrs = (float(lr_rot), float(lr_trans), float(lr_exposure))
+        self.betas, self.eps = betas, eps
+        dev = viewpoint.cam_rot_delta.device
+        self.m = torch.zeros(8, device=dev)
+        self.v = torch.zeros(8, device=dev)
+        self.out = torch.zeros(2, device=dev)
+        self.t = 0
+
+    def zero_grad(self):
+        vp = self.vp
+        for p in (vp.cam_rot_delta, vp.cam_trans_delta, vp.exposure_a, vp.exposure_b):
+            p.grad = None
+
+    @torch.no_grad()
+    def step_and_retract(self, converged_threshold=1e-4, sync=True):
+        """Returns the convergence flag (bool) when ``sync`` else the device tensor out[2]."""
+        lib = _lib.load()
+        vp = self.vp
+        self.t += 1
+        R = vp.R.contiguous() if not vp.R.is_contiguous() else vp.R
+        T = vp.T.contiguous() if not vp.T.is_contiguous() else vp.T
+        if R.data_ptr() != vp.R.data_ptr() or T.data_ptr() != vp.T.data_ptr():
+            vp.R, vp.T = R, T
+        g = lambda p: None if p.grad is None else p.grad.contiguous().data_ptr()  # noqa: E731
+        with torch.cuda.device(R.device):
+            _lib.check(lib.mgs_pose_step(R.data_ptr(), T.data_ptr(), vp.cam_rot_delta.data_ptr(),
+                                         vp.cam_trans_delta.data_ptr(), vp.exposure_a.data_ptr(),
+                                         vp.exposure_b.data_ptr(), g(vp.cam_rot_delta), g(vp.cam_trans_delta),
+                                         g(vp.exposure_a), g(vp.exposure_b), self.m.data_ptr(), self.v.data_ptr(),
+                                         self.t, self.lrs[0], self.lrs[1], self.lrs[2], self.betas[0], self.betas[1],
+                                         self.eps, float(converged_threshold), self.out.data_ptr(), _stream()),
+                       "mgs_pose_step")
+        return bool(self.out[0].item() > 0.5) if sync else self.out

@@ -28,6 +28,7 @@ from . import camera as cam
 from .knn import distCUDA2
 from .renderer import render
 from . import fused_losses, slam_losses
+from .pose_optim import PoseAdam
 from .synthetic import make_scene
 
 
@@ -176,7 +177,7 @@ def make_sequence(n_frames: int, intrinsics="fr3_office", n_gaussians=60000, see
 
 def run_slam(n_frames=12, intrinsics="fr3_office", tracking_itr_num=100, mapping_itr_num=150, window_size=8,
              kf_interval=4, init_itr_num=300, n_gaussians=60000, device="cuda:0", log=None,
-             init_downsample=8, kf_downsample=16, point_size=1.0, fused_losses_on=True):
+             init_downsample=8, kf_downsample=16, point_size=1.0, fused_losses_on=True, fused_pose_on=True):
     """Returns a dict with tracking / mapping FPS, iterations and the trajectory error."""
     frames, intr = make_sequence(n_frames, intrinsics, n_gaussians, device=device)
     L = fused_losses if fused_losses_on else slam_losses
@@ -191,7 +192,8 @@ def run_slam(n_frames=12, intrinsics="fr3_office", tracking_itr_num=100, mapping
 
     def map_window(iters, init=False):
         pose_params = []
-        for vp in window[1:] if len(window) > 1 else []:
+        fused_kf = [PoseAdam(vp, 0.003 * 0.5, 0.001 * 0.5, 0.01) for vp in window[1:]] if fused_pose_on else []
+        for vp in window[1:] if (len(window) > 1 and not fused_pose_on) else []:
             pose_params += [{"params": [vp.cam_rot_delta], "lr": 0.003 * 0.5},
                             {"params": [vp.cam_trans_delta], "lr": 0.001 * 0.5},
                             {"params": [vp.exposure_a], "lr": 0.01}, {"params": [vp.exposure_b], "lr": 0.01}]
@@ -211,6 +213,9 @@ def run_slam(n_frames=12, intrinsics="fr3_office", tracking_itr_num=100, mapping
                     kf_opt.zero_grad(set_to_none=True)
                     for vp in window[1:]:
                         vp.retract()
+                for pa in fused_kf:
+                    pa.step_and_retract(sync=False)
+                    pa.zero_grad()
             stats["map_iters"] += 1
 
     for i, vp in enumerate(frames):
@@ -225,9 +230,12 @@ def run_slam(n_frames=12, intrinsics="fr3_office", tracking_itr_num=100, mapping
             continue
         # ---- tracking (pose only; the Gaussians still require grad, as in the reference)
         prev = frames[i - 1]
-        vp.update_RT(prev.R, prev.T)
-        opt = torch.optim.Adam([{"params": [vp.cam_rot_delta], "lr": 0.003}, {"params": [vp.cam_trans_delta], "lr": 0.001},
-                                {"params": [vp.exposure_a], "lr": 0.01}, {"params": [vp.exposure_b], "lr": 0.01}])
+        vp.update_RT(prev.R.clone(), prev.T.clone())     # the fused pose step updates R, T in place
+        if fused_pose_on:
+            opt = PoseAdam(vp, 0.003, 0.001, 0.01)
+        else:
+            opt = torch.optim.Adam([{"params": [vp.cam_rot_delta], "lr": 0.003}, {"params": [vp.cam_trans_delta], "lr": 0.001},
+                                    {"params": [vp.exposure_a], "lr": 0.01}, {"params": [vp.exposure_b], "lr": 0.01}])
         sync(); t0 = time.perf_counter()
         for it in range(tracking_itr_num):
             pkg = _render(vp, intr, gmap, bg)
@@ -235,8 +243,11 @@ def run_slam(n_frames=12, intrinsics="fr3_office", tracking_itr_num=100, mapping
             loss = get_loss_tracking(pkg["render"], pkg["depth"], pkg["opacity"], vp)
             loss.backward()
             with torch.no_grad():
-                opt.step()
-                conv = vp.retract()
+                if fused_pose_on:
+                    conv = opt.step_and_retract()
+                else:
+                    opt.step()
+                    conv = vp.retract()
             stats["track_iters"] += 1
             stats["renders"] += 1
             if conv:
@@ -272,7 +283,7 @@ def run_slam(n_frames=12, intrinsics="fr3_office", tracking_itr_num=100, mapping
                mapping_iters_per_s=stats["map_iters"] / max(stats["map_s"], 1e-9),
                mapping_kf_per_s=stats["keyframes"] / max(stats["map_s"], 1e-9),
                ate_rmse_m=float(torch.sqrt((err ** 2).mean())),
-               fused_losses=bool(fused_losses_on),
+               fused_losses=bool(fused_losses_on), fused_pose=bool(fused_pose_on),
                config=dict(tracking_itr_num=tracking_itr_num, mapping_itr_num=mapping_itr_num,
                            window_size=window_size, kf_interval=kf_interval, init_itr_num=init_itr_num))
     return out

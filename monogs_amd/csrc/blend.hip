@@ -166,7 +166,7 @@ __device__ __forceinline__ float dpp_add(float v) {
 // ---- packed reduction of 10 per-lane values over the 64 lanes --------------------------------
 // stage 1: v_permlane32_swap pairs (x, y): lanes 0-31 then hold x[l]+x[l+32], lanes 32-63 y[l-32]+y[l]
 // stage 2: v_permlane16_swap pairs those: each 16-lane row then holds 16 partials of ONE value
-// stage 3: row-local DPP sum -> lane 15 of each row
+// stage 3: row-local butterfly sum through ds_swizzle -> every lane of each row
 __device__ __forceinline__ float swap32_add(float x, float y) {
     auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
@@ -175,11 +175,20 @@ __device__ __forceinline__ float swap16_add(float x, float y) {
     auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
-__device__ __forceinline__ float row_sum_to_lane15(float v) {
-    v = dpp_add<0x111, 0xf>(v);   // row_shr:1
-    v = dpp_add<0x112, 0xf>(v);   // row_shr:2
-    v = dpp_add<0x114, 0xf>(v);   // row_shr:4
-    v = dpp_add<0x118, 0xf>(v);   // row_shr:8
+// Sum over each 16-lane row, result in EVERY lane of the row.  The four exchange steps go through
+// ds_swizzle (LDS crossbar, its own issue port) instead of DPP: measured on gfx950 a v_add_f32_dpp costs
+// ~7.9 cycles of VALU issue against ~2.9 for a plain v_add_f32 (tools/ubench/valu_rate.hip), and this
+// kernel is VALU-issue-bound, so the butterfly's data movement is moved off the VALU.
+template <int XOR>
+__device__ __forceinline__ float swz_add(float v) {
+    // bit-mask mode: lane' = ((lane & 0x1f) | 0) ^ XOR within each half-wave
+    return v + __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x001F | (XOR << 10)));
+}
+__device__ __forceinline__ float row_sum_all(float v) {
+    v = swz_add<1>(v);
+    v = swz_add<2>(v);
+    v = swz_add<4>(v);
+    v = swz_add<8>(v);
     return v;
 }
 template <int CTRL>
@@ -187,9 +196,9 @@ __device__ __forceinline__ float dpp_mov(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
 }
 // Where reduce10 leaves value k (k = gradient slot G_SX..G_DDEPTH):
-//   lane 15: a0   lane 31: a2   lane 47: a1   lane 63: a3      (register c0)
-//   lane  0: a4   lane 16: a6   lane 32: a5   lane 48: a7      (c1 rotated right by 1 inside rows)
-//   lane  1: a8   lane 33: a9                                  (c2 rotated right by 2)
+//   lane 15: a0   lane 31: a2   lane 47: a1   lane 63: a3      (register c0, row sums in every lane)
+//   lane  0: a4   lane 16: a6   lane 32: a5   lane 48: a7      (register c1)
+//   lane  1: a8   lane 33: a9                                  (register c2)
 __device__ __forceinline__ int reduce10_slot(int lane) {
     const int row = lane >> 4, pos = lane & 15;
     if (pos == 15) return row == 0 ? 0 : row == 1 ? 2 : row == 2 ? 1 : 3;
@@ -204,13 +213,11 @@ __device__ __forceinline__ float reduce10(float a0, float a1, float a2, float a3
     float c0 = swap16_add(b0, b1);     // rows: a0 a2 a1 a3
     float c1 = swap16_add(b2, b3);     // rows: a4 a6 a5 a7
     float c2 = swap16_add(b4, b4);     // rows: a8 a8 a9 a9
-    c0 = row_sum_to_lane15(c0);
-    c1 = row_sum_to_lane15(c1);
-    c2 = row_sum_to_lane15(c2);
-    const float c1r = dpp_mov<0x121>(c1);   // row_ror:1 -> lane 0 of each row
-    const float c2r = dpp_mov<0x122>(c2);   // row_ror:2 -> lane 1 of each row
+    c0 = row_sum_all(c0);
+    c1 = row_sum_all(c1);
+    c2 = row_sum_all(c2);
     const int pos = lane & 15;
-    return pos == 15 ? c0 : (pos == 0 ? c1r : c2r);
+    return pos == 15 ? c0 : (pos == 0 ? c1 : c2);
 }
 
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {

@@ -20,6 +20,8 @@
 // alpha < 1/255 and the per-pixel rule would have skipped it too.
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace mgs {
 
 __device__ __forceinline__ uint32_t bcast(uint32_t v, int lane) {
@@ -226,38 +228,56 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
     return v;
 }
 
-__global__ void __launch_bounds__(256) blend_backward_kernel(BlendArgs a, const float* __restrict__ final_T,
+// NQ = 1: a wave owns ONE 8x8 quadrant of its tile (4 waves per tile; best when the image has few tiles).
+// NQ = 4: a wave owns the WHOLE 16x16 tile, four pixels per lane (lane l holds local pixel l of each
+//         quadrant).  Quadrants the instance's box misses are skipped with a wave-uniform branch, so the
+//         per-pixel arithmetic is the same as with NQ = 1, but the record fetch, the 10-value wave reduction
+//         and the atomic happen once per (instance, tile) instead of once per (instance, quadrant).
+template <int NQ>
+__global__ void __launch_bounds__(256) blend_backward_kernel(BlendArgs a, int ntiles,
+                                                             const float* __restrict__ final_T,
                                                              const uint32_t* __restrict__ n_contrib,
                                                              const float* __restrict__ dL_dcolor,
                                                              const float* __restrict__ dL_ddepth,
                                                              float* __restrict__ grad_acc) {
-    const int tile = blockIdx.x;
-    const int tx = tile % a.gx, ty = tile / a.gx;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int qx0i = tx * TILE + (wave & 1) * SUB, qy0i = ty * TILE + (wave >> 1) * SUB;
-    const int pxi = qx0i + (lane & 7), pyi = qy0i + (lane >> 3);
-    const bool inside = pxi < a.W && pyi < a.H;
-    const float pxf = (float)pxi, pyf = (float)pyi;
-    const float qx0 = (float)qx0i, qy0 = (float)qy0i;
+    const int tile = NQ == 1 ? (int)blockIdx.x : (int)blockIdx.x * 4 + wave;
+    if (tile >= ntiles) return;
+    const int tx = tile % a.gx, ty = tile / a.gx;
     const uint2 range = a.ranges[tile];
     if (range.y <= range.x) return;
+    const size_t HW = (size_t)a.H * a.W;
+    const float bg0 = a.bg[0], bg1 = a.bg[1], bg2 = a.bg[2];
 
-    const size_t pix = (size_t)pyi * a.W + pxi, HW = (size_t)a.H * a.W;
-    const float T_final = inside ? final_T[pix] : 0.f;
-    const uint32_t last = inside ? n_contrib[pix] : 0u;
-    const float g0 = inside ? dL_dcolor[pix] : 0.f;
-    const float g1 = inside ? dL_dcolor[HW + pix] : 0.f;
-    const float g2 = inside ? dL_dcolor[2 * HW + pix] : 0.f;
-    const float gd = inside ? dL_ddepth[pix] : 0.f;
-    const float bgT = -T_final * (a.bg[0] * g0 + a.bg[1] * g1 + a.bg[2] * g2);   // background term, per pixel
-
-    const uint32_t maxc = wave_max_u32(last);   // wave-uniform
+    // per-pixel state, one set per quadrant handled by this wave
+    float pxf[NQ], pyf[NQ], qx0[NQ], qy0[NQ], T_final[NQ], g0[NQ], g1[NQ], g2[NQ], gd[NQ], bgT[NQ];
+    float T[NQ], A[NQ], last_alpha[NQ], last_q[NQ];
+    uint32_t last[NQ];
+    uint32_t lmax = 0;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int quad = NQ == 1 ? wave : q;
+        const int qx0i = tx * TILE + (quad & 1) * SUB, qy0i = ty * TILE + (quad >> 1) * SUB;
+        const int pxi = qx0i + (lane & 7), pyi = qy0i + (lane >> 3);
+        const bool inside = pxi < a.W && pyi < a.H;
+        const size_t pix = (size_t)pyi * a.W + pxi;
+        pxf[q] = (float)pxi; pyf[q] = (float)pyi; qx0[q] = (float)qx0i; qy0[q] = (float)qy0i;
+        T_final[q] = inside ? final_T[pix] : 0.f;
+        last[q] = inside ? n_contrib[pix] : 0u;
+        g0[q] = inside ? dL_dcolor[pix] : 0.f;
+        g1[q] = inside ? dL_dcolor[HW + pix] : 0.f;
+        g2[q] = inside ? dL_dcolor[2 * HW + pix] : 0.f;
+        gd[q] = inside ? dL_ddepth[pix] : 0.f;
+        bgT[q] = -T_final[q] * (bg0 * g0[q] + bg1 * g1[q] + bg2 * g2[q]);   // background term, per pixel
+        T[q] = T_final[q];
+        A[q] = 0.f;           // sum over channels of (colour behind) * dL/dpixel, blended back to front
+        last_alpha[q] = 0.f;
+        last_q[q] = 0.f;
+        lmax = max(lmax, last[q]);
+    }
+    const uint32_t maxc = wave_max_u32(lmax);   // wave-uniform
     if (maxc == 0) return;
     const int slot = reduce10_slot(lane);
-
-    float T = T_final;
-    float A = 0.f;            // sum over channels of (colour behind) * dL/dpixel, blended back to front
-    float last_alpha = 0.f, last_q = 0.f;
     const uint32_t end = range.x + maxc;
 
     uint32_t gid_n = 0;
@@ -276,42 +296,68 @@ __global__ void __launch_bounds__(256) blend_backward_kernel(BlendArgs a, const 
         const uint32_t gid_l = gid_n;
         const float4 c = box_n;
         prefetch(b - 1);
-        const bool hit = (c.x + c.z >= qx0) && (c.x - c.z <= qx0 + (float)(SUB - 1)) && (c.y + c.w >= qy0) &&
-                         (c.y - c.w <= qy0 + (float)(SUB - 1));
-        unsigned long long mask = __ballot(hit);
+        unsigned long long qmask[NQ], mask = 0ull;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const bool hit = (c.x + c.z >= qx0[q]) && (c.x - c.z <= qx0[q] + (float)(SUB - 1)) &&
+                             (c.y + c.w >= qy0[q]) && (c.y - c.w <= qy0[q] + (float)(SUB - 1));
+            qmask[q] = __ballot(hit);
+            mask |= qmask[q];
+        }
         while (mask) {
             const int j = 63 - __builtin_clzll(mask);
             mask &= ~(1ull << j);
             const uint32_t k = (uint32_t)b * WAVE + (uint32_t)j + 1u;     // 1-based position in the tile list
             const uint32_t gid = bcast(gid_l, j);
             const Rec g = fetch(a, gid);
-            const float dx = g.px - pxf, dy = g.py - pyf;
-            const float power = -0.5f * (g.ca * dx * dx + g.cc * dy * dy) - g.cb * dx * dy;
-            const float G = __expf(power);
-            const float alpha = fminf(0.99f, g.op * G);
-            const bool act = (k <= last) && !(power > 0.f) && !(alpha < 1.0f / 255.0f);
-            if (__ballot(act) == 0ull) continue;
-
-            // Everything below runs for all 64 lanes; an inactive lane contributes exact zeros
-            // (w = 0, h = 0) and keeps its state.
-            const float inv = __builtin_amdgcn_rcpf(1.f - alpha);   // v_rcp_f32, not the IEEE divide sequence
-            const float Tn = T * inv;
-            const float q = (g.r * g0 + g.g * g1) + (g.b * g2 + g.z * gd);
-            const float An = A + last_alpha * (last_q - A);          // = last_alpha*last_q + (1-last_alpha)*A
-            const float dL_dalpha = (q - An) * Tn + bgT * inv;
-            const float w = act ? alpha * Tn : 0.f;
-            const float h = act ? G * dL_dalpha : 0.f;               // g.op and the conic are applied per Gaussian later
-            T = act ? Tn : T;
-            A = act ? An : A;
-            last_q = act ? q : last_q;
-            last_alpha = act ? alpha : last_alpha;
-            const float hx = h * dx, hy = h * dy;
-            // ---- 10 wave sums in 28 VALU ops, then ONE atomic instruction with 10 active lanes
-            //      covering the Gaussian's 64-byte gradient line
-            const float m = reduce10(hx, hy, hx * dx, hx * dy, hy * dy, h, w * g0, w * g1, w * g2, w * gd, lane);
+            // partial sums of this instance over the wave's pixels (see the G_S* slots in common.h)
+            float s_x = 0.f, s_y = 0.f, s_xx = 0.f, s_xy = 0.f, s_yy = 0.f, s_h = 0.f;
+            float s_r = 0.f, s_g = 0.f, s_b = 0.f, s_z = 0.f;
+            bool any_act = false;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                if (NQ > 1 && ((qmask[q] >> j) & 1ull) == 0ull) continue;      // wave-uniform: box misses this quadrant
+                const float dx = g.px - pxf[q], dy = g.py - pyf[q];
+                const float power = -0.5f * (g.ca * dx * dx + g.cc * dy * dy) - g.cb * dx * dy;
+                const float G = __expf(power);
+                const float alpha = fminf(0.99f, g.op * G);
+                const bool act = (k <= last[q]) && !(power > 0.f) && !(alpha < 1.0f / 255.0f);
+                if (__ballot(act) == 0ull) continue;
+                any_act = true;
+                // Everything below runs for all 64 lanes; an inactive lane contributes exact zeros
+                // (w = 0, h = 0) and keeps its state.
+                const float inv = __builtin_amdgcn_rcpf(1.f - alpha);   // v_rcp_f32, not the IEEE divide sequence
+                const float Tn = T[q] * inv;
+                const float qq = (g.r * g0[q] + g.g * g1[q]) + (g.b * g2[q] + g.z * gd[q]);
+                const float An = A[q] + last_alpha[q] * (last_q[q] - A[q]);   // = la*lq + (1-la)*A
+                const float dL_dalpha = (qq - An) * Tn + bgT[q] * inv;
+                const float w = act ? alpha * Tn : 0.f;
+                const float h = act ? G * dL_dalpha : 0.f;   // g.op and the conic are applied per Gaussian later
+                T[q] = act ? Tn : T[q];
+                A[q] = act ? An : A[q];
+                last_q[q] = act ? qq : last_q[q];
+                last_alpha[q] = act ? alpha : last_alpha[q];
+                const float hx = h * dx, hy = h * dy;
+                s_x += hx; s_y += hy; s_h += h;
+                s_xx += hx * dx; s_xy += hx * dy; s_yy += hy * dy;
+                s_r += w * g0[q]; s_g += w * g1[q]; s_b += w * g2[q]; s_z += w * gd[q];
+            }
+            if (!any_act) continue;
+            // ---- 10 wave sums (two swap stages + a ds_swizzle butterfly), then ONE atomic instruction with
+            //      10 active lanes covering the Gaussian's 64-byte gradient line
+            const float m = reduce10(s_x, s_y, s_xx, s_xy, s_yy, s_h, s_r, s_g, s_b, s_z, lane);
             if (slot >= 0) atomicAdd(grad_acc + (size_t)gid * GRAD_FLOATS + slot, m);
         }
     }
+}
+
+// Measured on MI355X (round 1): the wave-per-tile variant is SLOWER than wave-per-quadrant at every size
+// tried (C5 1080p / 2 M: 0.63 vs 0.59 ms; VGA / 100 k: 0.148 vs 0.092 ms) -- 91 VGPRs (5 waves per SIMD instead
+// of 8), walks bounded by the tile's deepest pixel instead of the quadrant's, and only 8160 long-running
+// waves.  It stays as an opt-in experiment (MGS_TILE_PER_WAVE=1) with parity coverage; the default is NQ = 1.
+static int tile_per_wave(int) {
+    const char* e = getenv("MGS_TILE_PER_WAVE");
+    return e && e[0] == '1';
 }
 
 int launch_blend_backward(const mgs_camera& cam, const GeometryState& g, const BinningState& b,
@@ -320,8 +366,12 @@ int launch_blend_backward(const mgs_camera& cam, const GeometryState& g, const B
     const BlendArgs a = make_args(cam, g, b, img);
     const int ntiles = a.gx * tiles_y(a.H);
     if (ntiles == 0) return 0;
-    hipLaunchKernelGGL(blend_backward_kernel, dim3(ntiles), dim3(256), 0, s, a, img.final_T, img.n_contrib, dL_dcolor,
-                       dL_ddepth, grad_acc);
+    if (tile_per_wave(ntiles))
+        hipLaunchKernelGGL(blend_backward_kernel<4>, dim3((ntiles + 3) / 4), dim3(256), 0, s, a, ntiles, img.final_T,
+                           img.n_contrib, dL_dcolor, dL_ddepth, grad_acc);
+    else
+        hipLaunchKernelGGL(blend_backward_kernel<1>, dim3(ntiles), dim3(256), 0, s, a, ntiles, img.final_T,
+                           img.n_contrib, dL_dcolor, dL_ddepth, grad_acc);
     MGS_HIP(hipGetLastError());
     return 0;
 }

@@ -97,7 +97,7 @@ int mgs_forward_preprocess(const mgs_camera* cam, int32_t P,
                            const float* rotations,      /* [P,4] or NULL */
                            const float* cov3D_precomp,  /* [P,6] or NULL */
                            void* geometry, int32_t* radii /* [P] */,
-                           uint64_t* num_rendered /* [host] */,
+                           uint64_t* num_rendered /* [host]; NULL = capacity mode, no sync */,
                            mgs_timing* timing /* [host] or NULL */, void* stream);
 
 /* Forward, stage 2: duplicate (in depth order), stable grouping by tile, per-tile ranges, front-to-back blend.
@@ -107,6 +107,18 @@ int mgs_forward_render(const mgs_camera* cam, int32_t P, uint64_t num_rendered,
                        void* geometry, void* binning, void* image,
                        float* out_color, float* out_depth, float* out_opacity, int32_t* n_touched,
                        mgs_timing* timing, void* stream);
+
+/* Forward, stage 2 without a host-side instance count ("capacity mode"): call mgs_forward_preprocess with
+ * num_rendered = NULL (no read-back, no stream sync), size the binning scratch with
+ * mgs_binning_bytes(capacity, W, H) for a caller-chosen capacity (e.g. 1.5x the previous frame's count), and the
+ * kernels read the live count min(R, capacity) on the device.  If R > capacity the surplus instances are dropped
+ * and *overflow (device uint32, optional) is set to 1: the caller must re-render with a larger capacity.  The
+ * whole forward + backward then contains no host synchronisation and can be captured in a hipGraph.
+ * Pass the same `capacity` as num_rendered to mgs_backward. */
+int mgs_forward_render_capacity(const mgs_camera* cam, int32_t P, uint64_t capacity,
+                                void* geometry, void* binning, void* image,
+                                float* out_color, float* out_depth, float* out_opacity, int32_t* n_touched,
+                                uint32_t* overflow, mgs_timing* timing, void* stream);
 
 /* Backward.  Consumes dL/dcolor[3,H,W] and dL/ddepth[1,H,W] (dL/dopacity is ignored, as upstream) and
  * the scratch of the matching forward.  Any output pointer may be NULL (that gradient is then not
@@ -162,12 +174,15 @@ int mgs_loss_backward(int32_t width, int32_t height, int32_t tracking, int32_t i
  * torch.optim.Adam.step() on (cam_rot_delta lr_rot, cam_trans_delta lr_trans, exposure_a/b lr_exposure)
  * followed by update_pose (/root/reference/utils/pose_utils.py:76-93): T_cw <- exp([rho; theta]^) T_cw,
  * deltas reset to zero.  R[3,3] (row-major), T[3], the parameters and the Adam moments adam_m[8], adam_v[8]
- * (order rot(3), trans(3), a, b) are device tensors updated in place; `step` is the 1-based Adam step;
+ * (order rot(3), trans(3), a, b) are device tensors updated in place; `step` is the 1-based Adam step, or, when
+ * step_counter (device int32) is non-NULL, the counter is incremented on the device and used instead (so the call
+ * can be captured in a hipGraph and replayed);
  * out[2] = {converged (|tau| < converged_threshold ? 1 : 0), |tau|}.  exposure pointers / any gradient may be NULL. */
 int mgs_pose_step(float* R, float* T, float* rot_delta, float* trans_delta, float* exposure_a, float* exposure_b,
                   const float* grad_rot, const float* grad_trans, const float* grad_a, const float* grad_b,
                   float* adam_m, float* adam_v, int32_t step, float lr_rot, float lr_trans, float lr_exposure,
-                  float beta1, float beta2, float eps, float converged_threshold, float* out, void* stream);
+                  float beta1, float beta2, float eps, float converged_threshold, int32_t* step_counter, float* out,
+                  void* stream);
 
 #ifdef __cplusplus
 }

@@ -47,6 +47,8 @@ SIGNATURES = {
                                + [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(MgsTiming), C.c_void_p]),
     "mgs_forward_render": (C.c_int, [C.POINTER(MgsCamera), C.c_int32, C.c_uint64] + [C.c_void_p] * 7
                            + [C.POINTER(MgsTiming), C.c_void_p]),
+    "mgs_forward_render_capacity": (C.c_int, [C.POINTER(MgsCamera), C.c_int32, C.c_uint64] + [C.c_void_p] * 8
+                                    + [C.POINTER(MgsTiming), C.c_void_p]),
     "mgs_backward": (C.c_int, [C.POINTER(MgsCamera), C.c_int32, C.c_uint64] + [C.c_void_p] * 7
                      + [C.c_void_p] * 4 + [C.c_void_p] * 2 + [C.c_void_p] * 9
                      + [C.c_void_p, C.POINTER(MgsTiming), C.c_void_p]),
@@ -55,7 +57,7 @@ SIGNATURES = {
     "mgs_loss_forward": (C.c_int, [C.c_int32] * 4 + [C.c_float] + [C.c_void_p] * 9 + [C.c_void_p, C.c_void_p, C.c_void_p]),
     "mgs_loss_backward": (C.c_int, [C.c_int32] * 4 + [C.c_float] + [C.c_void_p] * 9
                           + [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "mgs_pose_step": (C.c_int, [C.c_void_p] * 12 + [C.c_int32] + [C.c_float] * 7 + [C.c_void_p, C.c_void_p]),
+    "mgs_pose_step": (C.c_int, [C.c_void_p] * 12 + [C.c_int32] + [C.c_float] * 7 + [C.c_void_p, C.c_void_p, C.c_void_p]),
     "mgs_knn_scratch_bytes": (C.c_size_t, [C.c_int32]),
     "mgs_dist2_knn": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
 }

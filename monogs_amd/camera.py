@@ -28,10 +28,9 @@ ZFAR = 100.0
 
 def world2view(R: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
     """4x4 world-to-camera matrix [[R, t], [0, 1]]; R, t are already world->camera."""
-    M = torch.zeros(4, 4, dtype=torch.float32, device=R.device)
+    M = torch.eye(4, dtype=torch.float32, device=R.device)     # (no host scalar writes: hipGraph-capturable)
     M[:3, :3] = R
     M[:3, 3] = t
-    M[3, 3] = 1.0
     return M
 
 

@@ -62,7 +62,7 @@ ImageState ImageState::carve(void* base, int W, int H) {
 
 size_t BinningState::bytes(uint64_t R, int W, int H) {
     const size_t r = (size_t)(R ? R : 1);
-    return align_up(r * 4, 256) * 4 + align_up(mgs::sort_temp_bytes(R, tile_bits(W, H)), 256) + 256;
+    return align_up(r * 4, 256) * 4 + align_up(mgs::sort_temp_bytes(R, tile_bits(W, H)), 256) + 256 + 256;
 }
 BinningState BinningState::carve(void* base, uint64_t R, int W, int H) {
     const size_t r = (size_t)(R ? R : 1);
@@ -77,6 +77,7 @@ BinningState BinningState::carve(void* base, uint64_t R, int W, int H) {
     b.vals_sorted = in_b ? b.vals_b : b.vals_a;
     b.sort_temp_bytes = mgs::sort_temp_bytes(R, tile_bits(W, H));
     b.sort_temp = take(p, b.sort_temp_bytes);
+    b.count = (uint32_t*)take(p, 2 * sizeof(uint32_t));
     return b;
 }
 
@@ -135,8 +136,7 @@ int mgs_forward_preprocess(const mgs_camera* cam, int32_t P, const float* means3
                            uint64_t* num_rendered, mgs_timing* timing, void* stream) {
     if (check_cam(cam)) return 1;
     if (P < 0) { set_error("P must be >= 0"); return 1; }
-    if (!num_rendered) { set_error("num_rendered is NULL"); return 1; }
-    *num_rendered = 0;
+    if (num_rendered) *num_rendered = 0;        // NULL = capacity mode: no read-back, no stream sync
     if (P == 0) return 0;
     if (!means3D || !opacities || !geometry || !radii) { set_error("means3D, opacities, geometry, radii must be non-NULL"); return 1; }
     if ((shs == nullptr) == (colors_precomp == nullptr)) {
@@ -163,11 +163,14 @@ int mgs_forward_preprocess(const mgs_camera* cam, int32_t P, const float* means3
     tm.mark();
     if (int rc = launch_scan(g, P, s)) return rc;
     tm.mark();
-    uint32_t total = 0;
-    MGS_HIP(hipMemcpyAsync(&total, g.point_offsets + (P - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    MGS_HIP(hipStreamSynchronize(s));
-    *num_rendered = total;
+    if (num_rendered) {
+        uint32_t total = 0;
+        MGS_HIP(hipMemcpyAsync(&total, g.point_offsets + (P - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        MGS_HIP(hipStreamSynchronize(s));
+        *num_rendered = total;
+    }
     if (timing) {
+        if (!num_rendered) MGS_HIP(hipStreamSynchronize(s));
         timing->preprocess_ms = tm.ms(0);
         timing->depth_sort_ms = tm.ms(1);
         timing->scan_ms = tm.ms(2);
@@ -175,9 +178,9 @@ int mgs_forward_preprocess(const mgs_camera* cam, int32_t P, const float* means3
     return 0;
 }
 
-int mgs_forward_render(const mgs_camera* cam, int32_t P, uint64_t R, void* geometry, void* binning, void* image,
-                       float* out_color, float* out_depth, float* out_opacity, int32_t* n_touched,
-                       mgs_timing* timing, void* stream) {
+static int forward_render_impl(const mgs_camera* cam, int32_t P, uint64_t R, bool capacity, void* geometry,
+                               void* binning, void* image, float* out_color, float* out_depth, float* out_opacity,
+                               int32_t* n_touched, uint32_t* overflow, mgs_timing* timing, void* stream) {
     if (check_cam(cam)) return 1;
     if (!image || !out_color || !out_depth || !out_opacity) { set_error("image scratch and outputs must be non-NULL"); return 1; }
     if (P > 0 && (!geometry || !n_touched)) { set_error("geometry and n_touched must be non-NULL"); return 1; }
@@ -188,16 +191,24 @@ int mgs_forward_render(const mgs_camera* cam, int32_t P, uint64_t R, void* geome
     GeometryState g = GeometryState::carve(geometry, P);
     ImageState img = ImageState::carve(image, W, H);
     BinningState b = BinningState::carve(binning, R, W, H);
+    const uint32_t* n_dev = nullptr;
     StageTimer tm(s, timing != nullptr);
     if (P > 0) MGS_HIP(hipMemsetAsync(n_touched, 0, (size_t)P * sizeof(int32_t), s));
-    tm.mark();
-    if (R > 0) {
-        if (int rc = launch_duplicate(*cam, P, g, b, s)) return rc;
+    if (capacity && binning) {
+        if (int rc = launch_clamp_count(g, P, R, b.count, s)) return rc;
+        n_dev = b.count;
+        if (overflow) MGS_HIP(hipMemcpyAsync(overflow, b.count + 1, sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+    } else if (overflow) {
+        MGS_HIP(hipMemsetAsync(overflow, 0, sizeof(uint32_t), s));
     }
     tm.mark();
-    if (int rc = launch_sort(b, R, tile_bits(W, H), s)) return rc;
+    if (R > 0) {
+        if (int rc = launch_duplicate(*cam, P, g, b, capacity ? R : 0xFFFFFFFFull, s)) return rc;
+    }
     tm.mark();
-    if (int rc = launch_ranges(b, R, img, tiles_x(W) * tiles_y(H), s)) return rc;
+    if (int rc = launch_sort(b, R, tile_bits(W, H), s, n_dev)) return rc;
+    tm.mark();
+    if (int rc = launch_ranges(b, R, img, tiles_x(W) * tiles_y(H), s, n_dev)) return rc;
     tm.mark();
     if (int rc = launch_blend_forward(*cam, g, b, img, out_color, out_depth, out_opacity, n_touched, s)) return rc;
     tm.mark();
@@ -209,6 +220,21 @@ int mgs_forward_render(const mgs_camera* cam, int32_t P, uint64_t R, void* geome
         timing->blend_fwd_ms = tm.ms(3);
     }
     return 0;
+}
+
+int mgs_forward_render(const mgs_camera* cam, int32_t P, uint64_t R, void* geometry, void* binning, void* image,
+                       float* out_color, float* out_depth, float* out_opacity, int32_t* n_touched,
+                       mgs_timing* timing, void* stream) {
+    return forward_render_impl(cam, P, R, false, geometry, binning, image, out_color, out_depth, out_opacity, n_touched,
+                               nullptr, timing, stream);
+}
+
+int mgs_forward_render_capacity(const mgs_camera* cam, int32_t P, uint64_t capacity, void* geometry, void* binning,
+                                void* image, float* out_color, float* out_depth, float* out_opacity,
+                                int32_t* n_touched, uint32_t* overflow, mgs_timing* timing, void* stream) {
+    if (capacity == 0) { set_error("capacity must be > 0"); return 1; }
+    return forward_render_impl(cam, P, capacity, true, geometry, binning, image, out_color, out_depth, out_opacity,
+                               n_touched, overflow, timing, stream);
 }
 
 int mgs_backward(const mgs_camera* cam, int32_t P, uint64_t R, const float* means3D, const float* shs,

@@ -111,7 +111,7 @@ __global__ void __launch_bounds__(256) duplicate_kernel(int P, const float* __re
                                                         const uint32_t* __restrict__ perm,
                                                         const uint32_t* __restrict__ offsets,
                                                         const uint32_t* __restrict__ tiles_touched, uint32_t* keys,
-                                                        uint32_t* vals, int gx, int gy) {
+                                                        uint32_t* vals, int gx, int gy, uint32_t r_cap) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
     const uint32_t idx = perm[i];
@@ -127,17 +127,37 @@ __global__ void __launch_bounds__(256) duplicate_kernel(int P, const float* __re
     const int y1 = min(gy, max(0, (int)(((py + radius) + (float)(TILE - 1)) / (float)TILE)));
     for (int y = y0; y < y1; ++y)
         for (int x = x0; x < x1; ++x) {
-            keys[off] = (uint32_t)(y * gx + x);
-            vals[off] = idx;
+            if (off < r_cap) {                       // capacity mode: never write past the buffers
+                keys[off] = (uint32_t)(y * gx + x);
+                vals[off] = idx;
+            }
             ++off;
         }
 }
 
-int launch_duplicate(const mgs_camera& cam, int P, const GeometryState& g, const BinningState& b, hipStream_t s) {
+__global__ void clamp_count_kernel(const uint32_t* __restrict__ offsets, int P, uint32_t r_cap, uint32_t* count) {
+    const uint32_t R = offsets[P - 1];
+    count[0] = min(R, r_cap);
+    count[1] = R > r_cap ? 1u : 0u;
+}
+
+int launch_clamp_count(const GeometryState& g, int P, uint64_t r_cap, uint32_t* count, hipStream_t s) {
+    if (P == 0) {
+        MGS_HIP(hipMemsetAsync(count, 0, 2 * sizeof(uint32_t), s));
+        return 0;
+    }
+    hipLaunchKernelGGL(clamp_count_kernel, dim3(1), dim3(1), 0, s, g.point_offsets, P,
+                       (uint32_t)(r_cap > 0xFFFFFFFFull ? 0xFFFFFFFFull : r_cap), count);
+    MGS_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_duplicate(const mgs_camera& cam, int P, const GeometryState& g, const BinningState& b, uint64_t r_cap,
+                     hipStream_t s) {
     if (P == 0) return 0;
     hipLaunchKernelGGL(duplicate_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, g.rec, g.perm, g.point_offsets,
-                       g.tiles_touched, b.keys_a, b.vals_a, tiles_x(cam.image_width),
-                       tiles_y(cam.image_height));
+                       g.tiles_touched, b.keys_a, b.vals_a, tiles_x(cam.image_width), tiles_y(cam.image_height),
+                       (uint32_t)(r_cap > 0xFFFFFFFFull ? 0xFFFFFFFFull : r_cap));
     MGS_HIP(hipGetLastError());
     return 0;
 }
@@ -151,15 +171,17 @@ int launch_depth_sort(const GeometryState& g, int P, hipStream_t s) {
     return radix_sort_pairs(g.depth_key, g.iota, g.depth_alt, g.iota_alt, (uint64_t)P, 32, g.sort_temp, s);
 }
 
-int launch_sort(const BinningState& b, uint64_t R, int bits, hipStream_t s) {
-    return radix_sort_pairs(b.keys_a, b.vals_a, b.keys_b, b.vals_b, R, bits, b.sort_temp, s);
+int launch_sort(const BinningState& b, uint64_t R, int bits, hipStream_t s, const uint32_t* n_dev) {
+    return radix_sort_pairs(b.keys_a, b.vals_a, b.keys_b, b.vals_b, R, bits, b.sort_temp, s, n_dev);
 }
 
 // ------------------------------------------------------------------------------------------------
 // tile ranges
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) ranges_kernel(uint64_t R, const uint32_t* __restrict__ keys, uint2* ranges) {
+__global__ void __launch_bounds__(256) ranges_kernel(uint64_t R, const uint32_t* __restrict__ n_dev,
+                                                     const uint32_t* __restrict__ keys, uint2* ranges) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n_dev) R = min(R, (uint64_t)n_dev[0]);
     if (i >= R) return;
     const uint32_t t = keys[i];
     if (i == 0) {
@@ -174,10 +196,12 @@ __global__ void __launch_bounds__(256) ranges_kernel(uint64_t R, const uint32_t*
     if (i == R - 1) ranges[t].y = (uint32_t)R;
 }
 
-int launch_ranges(const BinningState& b, uint64_t R, const ImageState& img, int ntiles, hipStream_t s) {
+int launch_ranges(const BinningState& b, uint64_t R, const ImageState& img, int ntiles, hipStream_t s,
+                  const uint32_t* n_dev) {
     MGS_HIP(hipMemsetAsync(img.ranges, 0, (size_t)ntiles * sizeof(uint2), s));
     if (R == 0) return 0;
-    hipLaunchKernelGGL(ranges_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, R, b.keys_sorted, img.ranges);
+    hipLaunchKernelGGL(ranges_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, R, n_dev, b.keys_sorted,
+                       img.ranges);
     MGS_HIP(hipGetLastError());
     return 0;
 }

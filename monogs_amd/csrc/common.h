@@ -74,6 +74,7 @@ struct BinningState {
     uint32_t* vals_sorted;     // = vals_a or vals_b: "point_list", Gaussian index per instance in blend order
     void* sort_temp;
     size_t sort_temp_bytes;
+    uint32_t* count;           // [2] capacity mode: live instance count, overflow flag
     static size_t bytes(uint64_t R, int W, int H);
     static BinningState carve(void* base, uint64_t R, int W, int H);
 };
@@ -109,15 +110,19 @@ int launch_preprocess_forward(const mgs_camera& cam, int P, const float* means3D
                               const float* rotations, const float* cov3D_precomp,
                               const GeometryState& g, int32_t* radii, hipStream_t s);
 int launch_scan(const GeometryState& g, int P, hipStream_t s);
-int launch_duplicate(const mgs_camera& cam, int P, const GeometryState& g, const BinningState& b, hipStream_t s);
+// `r_cap`: capacity of the binning buffers; `count` (device): [0] live instance count min(R, r_cap), [1] overflow flag
+int launch_clamp_count(const GeometryState& g, int P, uint64_t r_cap, uint32_t* count, hipStream_t s);
+int launch_duplicate(const mgs_camera& cam, int P, const GeometryState& g, const BinningState& b, uint64_t r_cap,
+                     hipStream_t s);
 size_t sort_temp_bytes(uint64_t n, int bits);
 size_t radix_temp_bytes(uint64_t n, int bits);
 bool radix_result_in_b(int bits);
 int radix_sort_pairs(uint32_t* ka, uint32_t* va, uint32_t* kb, uint32_t* vb, uint64_t n, int bits, void* temp,
-                     hipStream_t s);
+                     hipStream_t s, const uint32_t* n_dev = nullptr);
 int launch_depth_sort(const GeometryState& g, int P, hipStream_t s);
-int launch_sort(const BinningState& b, uint64_t R, int bits, hipStream_t s);
-int launch_ranges(const BinningState& b, uint64_t R, const ImageState& img, int ntiles, hipStream_t s);
+int launch_sort(const BinningState& b, uint64_t R, int bits, hipStream_t s, const uint32_t* n_dev = nullptr);
+int launch_ranges(const BinningState& b, uint64_t R, const ImageState& img, int ntiles, hipStream_t s,
+                  const uint32_t* n_dev = nullptr);
 int launch_blend_forward(const mgs_camera& cam, const GeometryState& g, const BinningState& b,
                          const ImageState& img, float* out_color, float* out_depth, float* out_opacity,
                          int32_t* n_touched, hipStream_t s);

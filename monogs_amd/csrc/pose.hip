@@ -22,7 +22,8 @@ struct PoseStepArgs {
     float* v;             // [8] Adam second moments
     float* out;           // [2] {converged (0/1), |tau|}
     float lr_rot, lr_trans, lr_exp, beta1, beta2, eps, converged_threshold;
-    int step;             // 1-based Adam step count of this update
+    int step;             // 1-based Adam step count of this update (used when step_dev is NULL)
+    int* step_dev;        // optional device counter: incremented here, so a captured graph replays correctly
 };
 
 __device__ __forceinline__ void mat3mul(const float* A, const float* B, float* C) {
@@ -33,7 +34,9 @@ __device__ __forceinline__ void mat3mul(const float* A, const float* B, float* C
 __global__ void pose_step_kernel(PoseStepArgs a) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     // ---- Adam (torch.optim.Adam defaults: no weight decay, no amsgrad), one scalar at a time
-    const float bc1 = 1.f - powf(a.beta1, (float)a.step), bc2 = 1.f - powf(a.beta2, (float)a.step);
+    int step = a.step;
+    if (a.step_dev) { step = a.step_dev[0] + 1; a.step_dev[0] = step; }
+    const float bc1 = 1.f - powf(a.beta1, (float)step), bc2 = 1.f - powf(a.beta2, (float)step);
     float p[8], g[8];
     for (int i = 0; i < 3; ++i) {
         p[i] = a.rot_delta[i];     g[i] = a.g_rot ? a.g_rot[i] : 0.f;
@@ -92,17 +95,17 @@ extern "C" int mgs_pose_step(float* R, float* T, float* rot_delta, float* trans_
                              float* exposure_b, const float* grad_rot, const float* grad_trans, const float* grad_a,
                              const float* grad_b, float* adam_m, float* adam_v, int32_t step, float lr_rot,
                              float lr_trans, float lr_exposure, float beta1, float beta2, float eps,
-                             float converged_threshold, float* out, void* stream) {
+                             float converged_threshold, int32_t* step_counter, float* out, void* stream) {
     if (!R || !T || !rot_delta || !trans_delta || !adam_m || !adam_v || !out) {
         set_error("R, T, rot_delta, trans_delta, adam_m, adam_v, out must be non-NULL");
         return 1;
     }
-    if (step < 1) { set_error("step is 1-based"); return 1; }
+    if (!step_counter && step < 1) { set_error("step is 1-based"); return 1; }
     PoseStepArgs a;
     a.R = R; a.T = T; a.rot_delta = rot_delta; a.trans_delta = trans_delta; a.exp_a = exposure_a; a.exp_b = exposure_b;
     a.g_rot = grad_rot; a.g_trans = grad_trans; a.g_a = grad_a; a.g_b = grad_b; a.m = adam_m; a.v = adam_v; a.out = out;
     a.lr_rot = lr_rot; a.lr_trans = lr_trans; a.lr_exp = lr_exposure; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
-    a.converged_threshold = converged_threshold; a.step = step;
+    a.converged_threshold = converged_threshold; a.step = step; a.step_dev = step_counter;
     hipLaunchKernelGGL(pose_step_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a);
     MGS_HIP(hipGetLastError());
     return 0;

@@ -71,9 +71,11 @@ struct RsShifts { int npasses; };
 
 // Digit counts of every pass in one read of the keys.  Each wave keeps a private copy of the
 // histograms in LDS (4x fewer same-address LDS atomics; the tile-id digits are low-entropy).
-__global__ void __launch_bounds__(RS_THREADS) rs_hist_kernel(const uint32_t* __restrict__ keys, uint32_t n, int npasses,
+__global__ void __launch_bounds__(RS_THREADS) rs_hist_kernel(const uint32_t* __restrict__ keys, uint32_t n,
+                                                             const uint32_t* __restrict__ n_dev, int npasses,
                                                              uint32_t* __restrict__ hist) {
     __shared__ uint32_t lh[RS_WAVES][RS_MAX_PASSES][RS_RADIX];
+    if (n_dev) n = min(n, n_dev[0]);          // capacity mode: the live count is on the device
     for (int i = threadIdx.x; i < RS_WAVES * RS_MAX_PASSES * RS_RADIX; i += RS_THREADS) (&lh[0][0][0])[i] = 0;
     __syncthreads();
     const int wv = threadIdx.x >> 6;
@@ -113,7 +115,8 @@ struct RsPassArgs {
     uint32_t* kout;
     const uint32_t* vin;
     uint32_t* vout;
-    uint32_t n;
+    uint32_t n;               // number of pairs (capacity when n_dev is set)
+    const uint32_t* n_dev;    // optional: live count on the device (<= n after clamping)
     int shift;
     const uint32_t* base;     // [256] exclusive global base of each digit for this pass
     uint64_t* status;         // [tiles][256]
@@ -136,7 +139,10 @@ __global__ void __launch_bounds__(RS_THREADS) rs_pass_kernel(RsPassArgs a) {
     __syncthreads();
     const uint32_t tile = s_tile;
     const uint32_t tile_start = tile * (uint32_t)RS_TILE;
-    const uint32_t tile_n = min((uint32_t)RS_TILE, a.n - tile_start);
+    const uint32_t n_live = a.n_dev ? min(a.n, a.n_dev[0]) : a.n;
+    if (tile_start >= n_live) return;        // capacity mode: tiles past the live count have nothing to do
+                                             // (tickets are dense, so no live tile ever looks back at them)
+    const uint32_t tile_n = min((uint32_t)RS_TILE, n_live - tile_start);
 
     // ---- load (wave-striped: item i of lane l of wave w is element w*1024 + i*64 + l of the tile) and rank
     uint32_t key[RS_ITEMS], val[RS_ITEMS], rank[RS_ITEMS];
@@ -267,13 +273,15 @@ __global__ void __launch_bounds__(RS_THREADS) rs_pass_kernel(RsPassArgs a) {
     }
 }
 
+// Sorts n pairs on key bits [0, bits).  With `n_dev` the live pair count is read on the device
+// (min(n, *n_dev)) and n is only the capacity that sizes grids and scratch: no host-side size needed.
 // Sorts n pairs on key bits [0, bits).  `ka`/`va` hold the input; the passes ping-pong between
 // (ka, va) and (kb, vb).  The sorted pairs end in (kb, vb) when the number of passes is odd and in
 // (ka, va) when it is even (radix_result_in_b tells which).
 bool radix_result_in_b(int bits) { return (rs_passes(bits) & 1) != 0; }
 
 int radix_sort_pairs(uint32_t* ka, uint32_t* va, uint32_t* kb, uint32_t* vb, uint64_t n, int bits, void* temp,
-                     hipStream_t s) {
+                     hipStream_t s, const uint32_t* n_dev) {
     if (n == 0) return 0;
     if (n >= (1ull << 32)) { set_error("radix sort: more than 2^32-1 pairs"); return 1; }
     const int npasses = rs_passes(bits);
@@ -282,13 +290,13 @@ int radix_sort_pairs(uint32_t* ka, uint32_t* va, uint32_t* kb, uint32_t* vb, uin
     MGS_HIP(hipMemsetAsync(t.hist, 0, t.zero_bytes, s));
     const uint32_t tiles = rs_tiles(n);
     const uint32_t hist_blocks = min(tiles, 1024u);
-    hipLaunchKernelGGL(rs_hist_kernel, dim3(hist_blocks), dim3(RS_THREADS), 0, s, ka, (uint32_t)n, npasses, t.hist);
+    hipLaunchKernelGGL(rs_hist_kernel, dim3(hist_blocks), dim3(RS_THREADS), 0, s, ka, (uint32_t)n, n_dev, npasses, t.hist);
     hipLaunchKernelGGL(rs_scan_kernel, dim3(npasses), dim3(RS_RADIX), 0, s, t.hist, t.base);
     uint32_t *kin = ka, *vin = va, *kout = kb, *vout = vb;
     for (int p = 0; p < npasses; ++p) {
         RsPassArgs a;
         a.kin = kin; a.kout = kout; a.vin = vin; a.vout = vout;
-        a.n = (uint32_t)n; a.shift = 8 * p;
+        a.n = (uint32_t)n; a.n_dev = n_dev; a.shift = 8 * p;
         a.base = t.base + p * RS_RADIX;
         a.status = t.status + (size_t)p * tiles * RS_RADIX;
         a.ticket = t.tickets + p;

@@ -22,7 +22,7 @@ class PoseAdam:
         self.m = torch.zeros(8, device=dev)
         self.v = torch.zeros(8, device=dev)
         self.out = torch.zeros(2, device=dev)
-        self.t = 0
+        self.t_dev = torch.zeros(1, dtype=torch.int32, device=dev)     # Adam step count lives on the device
 
     def zero_grad(self):
         vp = self.vp
@@ -34,7 +34,6 @@ class PoseAdam:
         """Returns the convergence flag (bool) when ``sync`` else the device tensor out[2]."""
         lib = _lib.load()
         vp = self.vp
-        self.t += 1
         R = vp.R.contiguous() if not vp.R.is_contiguous() else vp.R
         T = vp.T.contiguous() if not vp.T.is_contiguous() else vp.T
         if R.data_ptr() != vp.R.data_ptr() or T.data_ptr() != vp.T.data_ptr():
@@ -45,7 +44,8 @@ class PoseAdam:
                                          vp.cam_trans_delta.data_ptr(), vp.exposure_a.data_ptr(),
                                          vp.exposure_b.data_ptr(), g(vp.cam_rot_delta), g(vp.cam_trans_delta),
                                          g(vp.exposure_a), g(vp.exposure_b), self.m.data_ptr(), self.v.data_ptr(),
-                                         self.t, self.lrs[0], self.lrs[1], self.lrs[2], self.betas[0], self.betas[1],
-                                         self.eps, float(converged_threshold), self.out.data_ptr(), _stream()),
+                                         0, self.lrs[0], self.lrs[1], self.lrs[2], self.betas[0], self.betas[1],
+                                         self.eps, float(converged_threshold), self.t_dev.data_ptr(),
+                                         self.out.data_ptr(), _stream()),
                        "mgs_pose_step")
         return bool(self.out[0].item() > 0.5) if sync else self.out

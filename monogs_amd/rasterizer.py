@@ -35,6 +35,41 @@ class GaussianRasterizationSettings(NamedTuple):
     debug: bool
 
 
+# ---- sync-free ("capacity") mode ----------------------------------------------------------------
+# The exact path reads the instance count R back to the host once per forward (as upstream does) to size the
+# binning scratch.  In capacity mode the scratch is sized from the LAST count seen for the same
+# (P, W, H) times a headroom factor, the kernels read the live count on the device, and nothing in
+# forward + backward synchronises the host -- which is what allows a whole tracking / mapping iteration to
+# be captured in a hipGraph (torch.cuda.graph).  An overflow (R > capacity) drops instances and sets a device
+# flag; `check_overflow()` (one sync, e.g. next to the convergence test of the pose step) reports it and raises
+# the capacity so the caller can redo the iteration.
+_sync_free = {"enabled": False, "headroom": 1.5}
+_capacity_hint: dict = {}
+_pending_overflow: list = []
+_graph_overflow: list = []      # flags of forwards recorded inside a hipGraph capture: re-checked on every call
+
+
+def set_sync_free(enabled: bool, headroom: float = 1.5):
+    _sync_free["enabled"], _sync_free["headroom"] = bool(enabled), float(headroom)
+
+
+def check_overflow() -> bool:
+    """True if any capacity-mode forward since the last call dropped instances (synchronises).
+    The capacity hints of the offending shapes are doubled."""
+    hit = False
+    for key, flag in _pending_overflow + _graph_overflow:
+        if int(flag.item()) != 0:
+            hit = True
+            _capacity_hint[key] = max(2 * _capacity_hint.get(key, 1), 1024)
+    _pending_overflow.clear()
+    return hit
+
+
+def clear_graph_flags():
+    """Forget the overflow flags of captured graphs (call when those graphs are destroyed)."""
+    _graph_overflow.clear()
+
+
 # ---- optional per-stage timing (bench.py) --------------------------------------------------
 _timing_sink: Optional[list] = None
 
@@ -113,17 +148,40 @@ class _RasterizeGaussians(torch.autograd.Function):
             color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
             depth = torch.empty(1, H, W, dtype=torch.float32, device=dev)
             opacity = torch.empty(1, H, W, dtype=torch.float32, device=dev)
-            num_rendered = C.c_uint64(0)
-            _lib.check(lib.mgs_forward_preprocess(
-                C.byref(cam), P, _ptr(means3D), _ptr(sh_), _ptr(col_), _ptr(opac_), _ptr(sc_), _ptr(rot_),
-                _ptr(cov_), geom.data_ptr(), radii.data_ptr(), C.byref(num_rendered), tref, _stream()),
-                "mgs_forward_preprocess")
-            R = int(num_rendered.value)
-            binning = torch.empty(lib.mgs_binning_bytes(R, W, H), **u8)
-            _lib.check(lib.mgs_forward_render(
-                C.byref(cam), P, R, geom.data_ptr(), binning.data_ptr(), img.data_ptr(), color.data_ptr(),
-                depth.data_ptr(), opacity.data_ptr(), n_touched.data_ptr(), tref, _stream()),
-                "mgs_forward_render")
+            key = (P, W, H)
+            capturing = torch.cuda.is_current_stream_capturing()
+            hint = _capacity_hint.get(key)
+            if capturing and hint is None:
+                raise RuntimeError("graph capture needs a capacity hint: run one eager forward with the same "
+                                   "(P, W, H) first")
+            if (capturing or _sync_free["enabled"]) and hint is not None and P > 0:
+                # ---- capacity mode: no read-back, no stream sync
+                R = max(int(hint * _sync_free["headroom"]) + 4096, 4096)
+                _lib.check(lib.mgs_forward_preprocess(
+                    C.byref(cam), P, _ptr(means3D), _ptr(sh_), _ptr(col_), _ptr(opac_), _ptr(sc_), _ptr(rot_),
+                    _ptr(cov_), geom.data_ptr(), radii.data_ptr(), None, tref, _stream()), "mgs_forward_preprocess")
+                binning = torch.empty(lib.mgs_binning_bytes(R, W, H), **u8)
+                overflow = torch.zeros(1, dtype=torch.int32, device=dev)
+                _lib.check(lib.mgs_forward_render_capacity(
+                    C.byref(cam), P, R, geom.data_ptr(), binning.data_ptr(), img.data_ptr(), color.data_ptr(),
+                    depth.data_ptr(), opacity.data_ptr(), n_touched.data_ptr(), overflow.data_ptr(), tref, _stream()),
+                    "mgs_forward_render_capacity")
+                (_graph_overflow if capturing else _pending_overflow).append((key, overflow))
+                ctx.overflow = overflow
+            else:
+                num_rendered = C.c_uint64(0)
+                _lib.check(lib.mgs_forward_preprocess(
+                    C.byref(cam), P, _ptr(means3D), _ptr(sh_), _ptr(col_), _ptr(opac_), _ptr(sc_), _ptr(rot_),
+                    _ptr(cov_), geom.data_ptr(), radii.data_ptr(), C.byref(num_rendered), tref, _stream()),
+                    "mgs_forward_preprocess")
+                R = int(num_rendered.value)
+                _capacity_hint[key] = R
+                binning = torch.empty(lib.mgs_binning_bytes(R, W, H), **u8)
+                _lib.check(lib.mgs_forward_render(
+                    C.byref(cam), P, R, geom.data_ptr(), binning.data_ptr(), img.data_ptr(), color.data_ptr(),
+                    depth.data_ptr(), opacity.data_ptr(), n_touched.data_ptr(), tref, _stream()),
+                    "mgs_forward_render")
+                ctx.overflow = None
             if timing is not None:
                 d = timing.as_dict()
                 d.update(kind="forward", num_rendered=R, P=P)

@@ -149,6 +149,51 @@ def _render(vp, intr, gmap: GaussianMap, bg):
     return render(vp, intr, gmap.get_xyz, gmap.get_rotation, gmap.get_scaling, gmap.get_opacity, gmap.get_features, bg)
 
 
+def _track_frame_graph(vp, intr, gmap, bg, max_iters):
+    """One frame of tracking with the iteration (render -> fused loss -> backward -> fused pose step) captured
+    in a hipGraph and replayed: the forward runs in capacity mode (no host sync), the Adam step count and the
+    convergence flag live on the device, so an iteration costs one graph launch plus one 4-byte read-back.
+    The map is constant during tracking, so its activations are evaluated once and it takes no gradient."""
+    from . import rasterizer as _r
+    with torch.no_grad():
+        xyz, rot, sca = gmap.get_xyz.detach(), gmap.get_rotation.detach(), gmap.get_scaling.detach()
+        opa, col = gmap.get_opacity.detach(), gmap.get_features.detach()
+    opt = PoseAdam(vp, 0.003, 0.001, 0.01)
+
+    def iteration():
+        pkg = render(vp, intr, xyz, rot, sca, opa, col, bg)
+        opt.zero_grad()
+        loss = fused_losses.get_loss_tracking(pkg["render"], pkg["depth"], pkg["opacity"], vp)
+        loss.backward()
+        opt.step_and_retract(sync=False)
+
+    # eager warm-up on a side stream (also records the capacity hint for this map size), then capture
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        iteration()
+    torch.cuda.current_stream().wait_stream(s)
+    n_it = 1
+    if bool(opt.out[0].item() > 0.5):
+        return n_it
+    graph = torch.cuda.CUDAGraph()
+    opt.zero_grad()
+    with torch.cuda.graph(graph):
+        iteration()
+    n_it += 1                                     # the capture pass does not execute; replay it once now
+    graph.replay()
+    while n_it < max_iters:
+        if bool(opt.out[0].item() > 0.5):
+            break
+        graph.replay()
+        n_it += 1
+    if _r.check_overflow():
+        raise RuntimeError("binning capacity overflow inside the captured tracking graph")
+    _r.clear_graph_flags()
+    del graph
+    return n_it
+
+
 def make_sequence(n_frames: int, intrinsics="fr3_office", n_gaussians=60000, seed=11, device="cuda:0"):
     """Ground-truth map + a smooth camera path; frames rendered by the rasteriser itself."""
     sc = make_scene(n_gaussians, intrinsics, seed=seed, near_fraction=0.0, mean_radius_px=9.0, device=device)
@@ -177,7 +222,7 @@ def make_sequence(n_frames: int, intrinsics="fr3_office", n_gaussians=60000, see
 
 def run_slam(n_frames=12, intrinsics="fr3_office", tracking_itr_num=100, mapping_itr_num=150, window_size=8,
              kf_interval=4, init_itr_num=300, n_gaussians=60000, device="cuda:0", log=None,
-             init_downsample=8, kf_downsample=16, point_size=1.0, fused_losses_on=True, fused_pose_on=True):
+             init_downsample=8, kf_downsample=16, point_size=1.0, fused_losses_on=True, fused_pose_on=True, graph_tracking=False):
     """Returns a dict with tracking / mapping FPS, iterations and the trajectory error."""
     frames, intr = make_sequence(n_frames, intrinsics, n_gaussians, device=device)
     L = fused_losses if fused_losses_on else slam_losses
@@ -231,13 +276,25 @@ def run_slam(n_frames=12, intrinsics="fr3_office", tracking_itr_num=100, mapping
         # ---- tracking (pose only; the Gaussians still require grad, as in the reference)
         prev = frames[i - 1]
         vp.update_RT(prev.R.clone(), prev.T.clone())     # the fused pose step updates R, T in place
+        if graph_tracking:
+            sync(); t0 = time.perf_counter()
+            n_it = _track_frame_graph(vp, intr, gmap, bg, tracking_itr_num)
+            sync(); stats["track_s"] += time.perf_counter() - t0
+            stats["track_iters"] += n_it
+            stats["renders"] += n_it
+            stats["tracked"] += 1
+            loss = torch.zeros(())
+            for p in gmap.params():
+                p.grad = None
+        else:
+            pass
         if fused_pose_on:
             opt = PoseAdam(vp, 0.003, 0.001, 0.01)
         else:
             opt = torch.optim.Adam([{"params": [vp.cam_rot_delta], "lr": 0.003}, {"params": [vp.cam_trans_delta], "lr": 0.001},
                                     {"params": [vp.exposure_a], "lr": 0.01}, {"params": [vp.exposure_b], "lr": 0.01}])
         sync(); t0 = time.perf_counter()
-        for it in range(tracking_itr_num):
+        for it in range(0 if graph_tracking else tracking_itr_num):
             pkg = _render(vp, intr, gmap, bg)
             opt.zero_grad()
             loss = get_loss_tracking(pkg["render"], pkg["depth"], pkg["opacity"], vp)
@@ -252,8 +309,9 @@ def run_slam(n_frames=12, intrinsics="fr3_office", tracking_itr_num=100, mapping
             stats["renders"] += 1
             if conv:
                 break
-        sync(); stats["track_s"] += time.perf_counter() - t0
-        stats["tracked"] += 1
+        if not graph_tracking:
+            sync(); stats["track_s"] += time.perf_counter() - t0
+            stats["tracked"] += 1
         for p in gmap.params():
             p.grad = None
         # ---- keyframe + mapping
@@ -283,7 +341,7 @@ def run_slam(n_frames=12, intrinsics="fr3_office", tracking_itr_num=100, mapping
                mapping_iters_per_s=stats["map_iters"] / max(stats["map_s"], 1e-9),
                mapping_kf_per_s=stats["keyframes"] / max(stats["map_s"], 1e-9),
                ate_rmse_m=float(torch.sqrt((err ** 2).mean())),
-               fused_losses=bool(fused_losses_on), fused_pose=bool(fused_pose_on),
+               fused_losses=bool(fused_losses_on), fused_pose=bool(fused_pose_on), graph_tracking=bool(graph_tracking),
                config=dict(tracking_itr_num=tracking_itr_num, mapping_itr_num=mapping_itr_num,
                            window_size=window_size, kf_interval=kf_interval, init_itr_num=init_itr_num))
     return out

@@ -206,3 +206,42 @@ def test_multiple_forwards_before_one_backward(native_lib):
         ref += og["means3D"]
     total.backward()
     assert ((means.grad.cpu() - ref).norm() / ref.norm()).item() < 1e-3
+
+
+def test_capacity_mode_matches_exact_path(native_lib):
+    """Sync-free forward (device-side instance count, capacity-sized scratch) gives the same images and
+    gradients as the exact path; an under-sized capacity raises the overflow flag instead of writing out of bounds."""
+    from monogs_amd import rasterizer as R
+    from monogs_amd.rasterizer import GaussianRasterizer
+    sc = make_scene(20000, "fr3_office", seed=131)
+    st = _hip_st(sc)
+
+    def run():
+        leaf = lambda t: t.to(DEV).clone().requires_grad_(True)  # noqa: E731
+        m, o, c, r = leaf(sc.means3D), leaf(sc.opacities), leaf(sc.colors), leaf(sc.rotations)
+        s = leaf(sc.scales.repeat(1, 3))
+        th = torch.zeros(3, device=DEV, requires_grad=True)
+        out = GaussianRasterizer(st)(means3D=m, means2D=torch.zeros_like(m), opacities=o, colors_precomp=c, scales=s,
+                                     rotations=r, theta=th, rho=torch.zeros(3, device=DEV, requires_grad=True))
+        ((out[0] * sc.grad_color.to(DEV)).sum() + (out[2] * sc.grad_depth.to(DEV)).sum()).backward()
+        return [x.detach().clone() for x in out], m.grad.clone(), th.grad.clone()
+
+    R.set_sync_free(False)
+    out_a, gm_a, gt_a = run()                       # exact path: records the capacity hint
+    try:
+        R.set_sync_free(True, headroom=1.2)
+        out_b, gm_b, gt_b = run()
+        assert not R.check_overflow()
+        for x, y in zip(out_a, out_b):
+            assert torch.equal(x, y)
+        assert torch.allclose(gm_a, gm_b, rtol=1e-4, atol=1e-9) and torch.allclose(gt_a, gt_b, rtol=1e-4, atol=1e-9)
+        # starve the capacity: the flag must fire, nothing may crash
+        key = (20000, 640, 480)
+        R._capacity_hint[key] = 1000
+        R.set_sync_free(True, headroom=1.0)
+        run()
+        assert R.check_overflow()
+        assert R._capacity_hint[key] >= 2000
+    finally:
+        R.set_sync_free(False)
+        R._capacity_hint.pop((20000, 640, 480), None)

@@ -85,7 +85,7 @@ __global__ void __launch_bounds__(256) blend_forward_kernel(BlendArgs a, float* 
         prefetch(base + WAVE + lane);
         const bool hit = (c.x + c.z >= qx0) && (c.x - c.z <= qx0 + (float)(SUB - 1)) && (c.y + c.w >= qy0) &&
                          (c.y - c.w <= qy0 + (float)(SUB - 1));
-        unsigned long long mask = __ballot(hit);
+        unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
         bool all_done = false;
         while (mask) {
             const int j = __builtin_ctzll(mask);
@@ -107,12 +107,12 @@ __global__ void __launch_bounds__(256) blend_forward_kernel(BlendArgs a, float* 
             Tf = contrib ? test_T : Tf;
             T = stop ? 0.f : (contrib ? test_T : T);
             last = contrib ? (base - range.x) + (uint32_t)j + 1u : last;
-            const unsigned long long touched = __ballot(contrib && test_T > 0.5f);
+            const unsigned long long touched = __builtin_amdgcn_ballot_w64(contrib && test_T > 0.5f);
             if (touched) {
                 if (lane == 0) atomicAdd(n_touched + gid, (int)__popcll(touched));
             }
-            if (__ballot(stop)) {                      // rare: re-check whether the whole quadrant is finished
-                if (__ballot(T != 0.f) == 0ull) { all_done = true; break; }
+            if (__builtin_amdgcn_ballot_w64(stop)) {                      // rare: re-check whether the whole quadrant is finished
+                if (__builtin_amdgcn_ballot_w64(T != 0.f) == 0ull) { all_done = true; break; }
             }
         }
         if (all_done) break;
@@ -301,7 +301,7 @@ __global__ void __launch_bounds__(256) blend_backward_kernel(BlendArgs a, int nt
         for (int q = 0; q < NQ; ++q) {
             const bool hit = (c.x + c.z >= qx0[q]) && (c.x - c.z <= qx0[q] + (float)(SUB - 1)) &&
                              (c.y + c.w >= qy0[q]) && (c.y - c.w <= qy0[q] + (float)(SUB - 1));
-            qmask[q] = __ballot(hit);
+            qmask[q] = __builtin_amdgcn_ballot_w64(hit);
             mask |= qmask[q];
         }
         while (mask) {
@@ -322,7 +322,7 @@ __global__ void __launch_bounds__(256) blend_backward_kernel(BlendArgs a, int nt
                 const float G = __expf(power);
                 const float alpha = fminf(0.99f, g.op * G);
                 const bool act = (k <= last[q]) && !(power > 0.f) && !(alpha < 1.0f / 255.0f);
-                if (__ballot(act) == 0ull) continue;
+                if (__builtin_amdgcn_ballot_w64(act) == 0ull) continue;
                 any_act = true;
                 // Everything below runs for all 64 lanes; an inactive lane contributes exact zeros
                 // (w = 0, h = 0) and keeps its state.
@@ -338,9 +338,15 @@ __global__ void __launch_bounds__(256) blend_backward_kernel(BlendArgs a, int nt
                 last_q[q] = act ? qq : last_q[q];
                 last_alpha[q] = act ? alpha : last_alpha[q];
                 const float hx = h * dx, hy = h * dy;
-                s_x += hx; s_y += hy; s_h += h;
-                s_xx += hx * dx; s_xy += hx * dy; s_yy += hy * dy;
-                s_r += w * g0[q]; s_g += w * g1[q]; s_b += w * g2[q]; s_z += w * gd[q];
+                if (NQ == 1) {          // a single quadrant: plain assignment, no accumulate
+                    s_x = hx; s_y = hy; s_h = h;
+                    s_xx = hx * dx; s_xy = hx * dy; s_yy = hy * dy;
+                    s_r = w * g0[q]; s_g = w * g1[q]; s_b = w * g2[q]; s_z = w * gd[q];
+                } else {
+                    s_x += hx; s_y += hy; s_h += h;
+                    s_xx += hx * dx; s_xy += hx * dy; s_yy += hy * dy;
+                    s_r += w * g0[q]; s_g += w * g1[q]; s_b += w * g2[q]; s_z += w * gd[q];
+                }
             }
             if (!any_act) continue;
             // ---- 10 wave sums (two swap stages + a ds_swizzle butterfly), then ONE atomic instruction with

@@ -159,11 +159,11 @@ __global__ void __launch_bounds__(RS_THREADS) rs_pass_kernel(RsPassArgs a) {
         const uint32_t e = (uint32_t)wv * (RS_ITEMS * WAVE) + (uint32_t)i * WAVE + lane;
         const bool valid = e < tile_n;
         const uint32_t d = (key[i] >> a.shift) & 0xFFu;
-        unsigned long long peers = __ballot(valid);
+        unsigned long long peers = __builtin_amdgcn_ballot_w64(valid);
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
             const bool bit = (d >> b) & 1u;
-            const unsigned long long bm = __ballot(valid && bit);
+            const unsigned long long bm = __builtin_amdgcn_ballot_w64(valid && bit);
             peers &= bit ? bm : ~bm;
         }
         rank[i] = 0;

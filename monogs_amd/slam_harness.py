@@ -89,8 +89,9 @@ class GaussianMap:
     """Isotropic RGB map with the reference's activations
     (/root/reference/gaussian_splatting/scene/gaussian_model.py:84-106)."""
 
-    def __init__(self, device):
+    def __init__(self, device, capturable=False):
         self.device = device
+        self.capturable = capturable        # torch.optim.Adam(capturable=True): step counters on the device (hipGraph)
         e = lambda *s: torch.empty(*s, device=device)  # noqa: E731
         self._xyz, self._rgb, self._opacity, self._scaling, self._rotation = e(0, 3), e(0, 3), e(0, 1), e(0, 1), e(0, 4)
         self.optimizer: Optional[torch.optim.Optimizer] = None
@@ -133,7 +134,8 @@ class GaussianMap:
         cat = [torch.cat([o.detach(), n], 0).requires_grad_(True) for o, n in zip(self.params(), new)]
         self._xyz, self._rgb, self._opacity, self._scaling, self._rotation = cat
         lrs = [1.6e-4 * 6.0, 0.0025, 0.05, 0.001, 0.001]   # position/feature/opacity/scaling/rotation lrs of the reference
-        self.optimizer = torch.optim.Adam([{"params": [p], "lr": lr} for p, lr in zip(self.params(), lrs)], eps=1e-15)
+        self.optimizer = torch.optim.Adam([{"params": [p], "lr": lr} for p, lr in zip(self.params(), lrs)], eps=1e-15,
+                                          capturable=self.capturable)
         # carry Adam moments of the old Gaussians over, zeros for the new ones (densification_postfix)
         for i, p in enumerate(self.params()):
             st = old_state.get(i)
@@ -222,13 +224,13 @@ def make_sequence(n_frames: int, intrinsics="fr3_office", n_gaussians=60000, see
 
 def run_slam(n_frames=12, intrinsics="fr3_office", tracking_itr_num=100, mapping_itr_num=150, window_size=8,
              kf_interval=4, init_itr_num=300, n_gaussians=60000, device="cuda:0", log=None,
-             init_downsample=8, kf_downsample=16, point_size=1.0, fused_losses_on=True, fused_pose_on=True, graph_tracking=False):
+             init_downsample=8, kf_downsample=16, point_size=1.0, fused_losses_on=True, fused_pose_on=True, graph_tracking=False, graph_mapping=False):
     """Returns a dict with tracking / mapping FPS, iterations and the trajectory error."""
     frames, intr = make_sequence(n_frames, intrinsics, n_gaussians, device=device)
     L = fused_losses if fused_losses_on else slam_losses
     get_loss_mapping, get_loss_tracking = L.get_loss_mapping, L.get_loss_tracking
     bg = torch.zeros(3, device=device)
-    gmap = GaussianMap(device)
+    gmap = GaussianMap(device, capturable=graph_mapping)
     window: List[Viewpoint] = []
     stats = dict(track_s=0.0, track_iters=0, tracked=0, map_s=0.0, map_iters=0, keyframes=0, renders=0)
 
@@ -243,6 +245,41 @@ def run_slam(n_frames=12, intrinsics="fr3_office", tracking_itr_num=100, mapping
                             {"params": [vp.cam_trans_delta], "lr": 0.001 * 0.5},
                             {"params": [vp.exposure_a], "lr": 0.01}, {"params": [vp.exposure_b], "lr": 0.01}]
         kf_opt = torch.optim.Adam(pose_params) if pose_params else None
+
+        def iteration():
+            loss = 0
+            for vp in window:
+                pkg = _render(vp, intr, gmap, bg)
+                loss = loss + get_loss_mapping(pkg["render"], pkg["depth"], vp, init=init)
+            loss.backward()
+            with torch.no_grad():
+                gmap.optimizer.step()
+                gmap.optimizer.zero_grad(set_to_none=True)
+                for pa in fused_kf:
+                    pa.step_and_retract(sync=False)
+                    pa.zero_grad()
+
+        if graph_mapping and fused_pose_on and fused_losses_on and iters >= 8:
+            # two eager iterations on a side stream (Adam state, capacity hints), then capture one and replay
+            from . import rasterizer as _r
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    iteration()
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                iteration()
+            for _ in range(iters - 2):
+                graph.replay()
+            stats["map_iters"] += iters
+            stats["renders"] += iters * len(window)
+            if _r.check_overflow():
+                raise RuntimeError("binning capacity overflow inside the captured mapping graph")
+            _r.clear_graph_flags()
+            del graph
+            return
         for _ in range(iters):
             loss = 0
             for vp in window:
@@ -341,7 +378,7 @@ def run_slam(n_frames=12, intrinsics="fr3_office", tracking_itr_num=100, mapping
                mapping_iters_per_s=stats["map_iters"] / max(stats["map_s"], 1e-9),
                mapping_kf_per_s=stats["keyframes"] / max(stats["map_s"], 1e-9),
                ate_rmse_m=float(torch.sqrt((err ** 2).mean())),
-               fused_losses=bool(fused_losses_on), fused_pose=bool(fused_pose_on), graph_tracking=bool(graph_tracking),
+               fused_losses=bool(fused_losses_on), fused_pose=bool(fused_pose_on), graph_tracking=bool(graph_tracking), graph_mapping=bool(graph_mapping),
                config=dict(tracking_itr_num=tracking_itr_num, mapping_itr_num=mapping_itr_num,
                            window_size=window_size, kf_interval=kf_interval, init_itr_num=init_itr_num))
     return out

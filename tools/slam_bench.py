@@ -26,6 +26,7 @@ if __name__ == "__main__":
     ap.add_argument("--mapping-iters", type=int, default=None)
     ap.add_argument("--gaussians", type=int, default=60000)
     ap.add_argument("--graph", action="store_true", help="capture the tracking iteration in a hipGraph (capacity mode)")
+    ap.add_argument("--eager-mapping", action="store_true", help="with --graph: capture tracking only")
     ap.add_argument("--torch-pose", action="store_true", help="torch.optim.Adam + Python retraction instead of mgs_pose_step")
     ap.add_argument("--torch-losses", action="store_true", help="use the plain PyTorch losses instead of the fused HIP ones")
     a = ap.parse_args()
@@ -34,7 +35,7 @@ if __name__ == "__main__":
     if a.mapping_iters is not None:
         cfg["mapping_itr_num"] = a.mapping_iters
     out = run_slam(n_frames=a.frames, init_itr_num=a.init_iters, n_gaussians=a.gaussians,
-                   fused_losses_on=not a.torch_losses, fused_pose_on=not a.torch_pose, graph_tracking=a.graph,
+                   fused_losses_on=not a.torch_losses, fused_pose_on=not a.torch_pose, graph_tracking=a.graph, graph_mapping=a.graph and not a.eager_mapping,
                    log=lambda s: print("[slam]", s, file=sys.stderr, flush=True), **cfg)
     out["workload"] = f"synthetic {a.config}-like sequence, {a.frames} frames"
     print(json.dumps(out))

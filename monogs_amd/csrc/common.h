@@ -19,12 +19,12 @@ constexpr int GRAD_FLOATS = 16;         // per-Gaussian gradient accumulator: on
 //   float4 #0 {px, py, ex, ey}   what a lane needs for the quadrant cull test
 //   float4 #1 {conic a, b, c, opacity}   } fetched with scalar loads for a surviving instance
 //   float4 #2 {r, g, b, depth}           }
-//   float4 #3 {cov_xx, cov_xy, cov_yy, radius}   backward / duplicate only
+//   float4 #3 {na, nb, nc, radius}   conic / (2 ln(255 o)) for the exact ellipse-vs-quadrant cull test; radius for duplicate
 enum : int {
     R_X = 0, R_Y = 1, R_EX = 2, R_EY = 3,
     R_CA = 4, R_CB = 5, R_CC = 6, R_OPAC = 7,
     R_R = 8, R_G = 9, R_B = 10, R_DEPTH = 11,
-    R_COVXX = 12, R_COVXY = 13, R_COVYY = 14, R_RADIUS = 15
+    R_NA = 12, R_NB = 13, R_NC = 14, R_RADIUS = 15
 };
 // gradient accumulator slots (float atomics by the blend backward).  With h = G * dL/dalpha summed
 // over the pixels of every tile the Gaussian touches, the blend backward stores the RAW moments

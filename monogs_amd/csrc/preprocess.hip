@@ -222,10 +222,13 @@ __global__ void __launch_bounds__(256) preprocess_forward_kernel(PreArgs a) {
     // kernels skip an instance for a whole 8x8 quadrant when the box misses the quadrant, which
     // cannot change any pixel because every skipped pair has alpha < 1/255.
     float ex = -1.f, ey = -1.f;
+    float na = 0.f, nb = 0.f, nc = 0.f;       // conic / (2 tau): the alpha >= 1/255 ellipse is  d^T N d <= 1
     const float tau = logf(255.0f * opac);
     if (tau > 0.f) {
         ex = sqrtf(2.f * tau * p.cxx) * 1.001f + 0.05f;
         ey = sqrtf(2.f * tau * p.cyy) * 1.001f + 0.05f;
+        const float it = 1.f / (2.f * tau);
+        na = ca * it; nb = cb * it; nc = cc * it;
     } else if (!(tau <= 0.f)) {   // NaN opacity: never skip, let the blend propagate it
         ex = ey = 3.0e38f;
     }
@@ -234,7 +237,7 @@ __global__ void __launch_bounds__(256) preprocess_forward_kernel(PreArgs a) {
     rec[0] = make_float4(px, py, ex, ey);
     rec[1] = make_float4(ca, cb, cc, opac);
     rec[2] = make_float4(rgb[0], rgb[1], rgb[2], pv[2]);
-    rec[3] = make_float4(p.cxx, p.cxy, p.cyy, radius);
+    rec[3] = make_float4(na, nb, nc, radius);
     a.radii[idx] = (int)radius;
     a.tiles_touched[idx] = (uint32_t)ntile;
     a.depth_key[idx] = __float_as_uint(pv[2]);   // > 0.2, so the bit pattern orders like the value

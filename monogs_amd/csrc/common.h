@@ -117,6 +117,7 @@ int launch_duplicate(const mgs_camera& cam, int P, const GeometryState& g, const
 size_t sort_temp_bytes(uint64_t n, int bits);
 size_t radix_temp_bytes(uint64_t n, int bits);
 bool radix_result_in_b(int bits);
+const uint32_t* radix_error_flag(void* temp, uint64_t n, int bits);
 int radix_sort_pairs(uint32_t* ka, uint32_t* va, uint32_t* kb, uint32_t* vb, uint64_t n, int bits, void* temp,
                      hipStream_t s, const uint32_t* n_dev = nullptr);
 int launch_depth_sort(const GeometryState& g, int P, hipStream_t s);

@@ -280,6 +280,9 @@ __global__ void __launch_bounds__(RS_THREADS) rs_pass_kernel(RsPassArgs a) {
 // (ka, va) when it is even (radix_result_in_b tells which).
 bool radix_result_in_b(int bits) { return (rs_passes(bits) & 1) != 0; }
 
+// device word that a timed-out look-back spin sets to 1 (checked by the caller at its next sync point)
+const uint32_t* radix_error_flag(void* temp, uint64_t n, int bits) { return rs_carve(temp, n ? n : 1, bits).error; }
+
 int radix_sort_pairs(uint32_t* ka, uint32_t* va, uint32_t* kb, uint32_t* vb, uint64_t n, int bits, void* temp,
                      hipStream_t s, const uint32_t* n_dev) {
     if (n == 0) return 0;

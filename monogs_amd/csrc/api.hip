@@ -196,7 +196,6 @@ static int forward_render_impl(const mgs_camera* cam, int32_t P, uint64_t R, boo
     BinningState b = BinningState::carve(binning, R, W, H);
     const uint32_t* n_dev = nullptr;
     StageTimer tm(s, timing != nullptr);
-    if (P > 0) MGS_HIP(hipMemsetAsync(n_touched, 0, (size_t)P * sizeof(int32_t), s));
     if (capacity && binning) {
         if (int rc = launch_clamp_count(g, P, R, b.count, s)) return rc;
         n_dev = b.count;
@@ -205,9 +204,8 @@ static int forward_render_impl(const mgs_camera* cam, int32_t P, uint64_t R, boo
         MGS_HIP(hipMemsetAsync(overflow, 0, sizeof(uint32_t), s));
     }
     tm.mark();
-    if (R > 0) {
-        if (int rc = launch_duplicate(*cam, P, g, b, capacity ? R : 0xFFFFFFFFull, s)) return rc;
-    }
+    // (also zeroes n_touched and the tile ranges; with R == 0 it emits nothing)
+    if (int rc = launch_duplicate(*cam, P, g, b, capacity ? R : (R > 0 ? 0xFFFFFFFFull : 0ull), n_touched, img, s)) return rc;
     tm.mark();
     if (int rc = launch_sort(b, R, tile_bits(W, H), s, n_dev)) return rc;
     tm.mark();
@@ -265,6 +263,7 @@ int mgs_backward(const mgs_camera* cam, int32_t P, uint64_t R, const float* mean
     float* grad_acc = (float*)align_up((size_t)backward_scratch, 256);
     StageTimer tm(s, timing != nullptr);
     MGS_HIP(hipMemsetAsync(grad_acc, 0, (size_t)P * GRAD_FLOATS * sizeof(float), s));
+    if (dL_dtau) MGS_HIP(hipMemsetAsync(dL_dtau, 0, 6 * sizeof(float), s));
     tm.mark();
     if (R > 0) {
         if (int rc = launch_blend_backward(*cam, g, b, img, dL_dcolor, dL_ddepth, grad_acc, s)) return rc;

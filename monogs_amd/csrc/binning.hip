@@ -90,8 +90,37 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_add_kernel(uint32_t* out, c
         if (base + i < n) out[base + i] += add;
 }
 
+// One workgroup, one launch: enough for SLAM-sized maps (three launches cost more than the scan itself)
+constexpr int SCAN_SMALL_THREADS = 1024;
+constexpr int SCAN_SMALL_MAX = SCAN_SMALL_THREADS * 64;
+__global__ void __launch_bounds__(SCAN_SMALL_THREADS) scan_small_kernel(const uint32_t* __restrict__ in,
+                                                                        const uint32_t* __restrict__ perm,
+                                                                        uint32_t* __restrict__ out, int n) {
+    __shared__ uint32_t wsum[SCAN_SMALL_THREADS / 64];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int per = (n + SCAN_SMALL_THREADS - 1) / SCAN_SMALL_THREADS;
+    const int b = t * per, e = min(n, b + per);
+    uint32_t sum = 0;
+    for (int i = b; i < e; ++i) sum += in[perm[i]];
+    const uint32_t incl = wave_incl_scan(sum, lane);
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    uint32_t run = incl - sum;
+    for (int w = 0; w < wv; ++w) run += wsum[w];
+    for (int i = b; i < e; ++i) {
+        run += in[perm[i]];
+        out[i] = run;
+    }
+}
+
 int launch_scan(const GeometryState& g, int P, hipStream_t s) {
     if (P == 0) return 0;
+    if (P <= SCAN_SMALL_MAX) {
+        hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(SCAN_SMALL_THREADS), 0, s, g.tiles_touched, g.perm,
+                           g.point_offsets, P);
+        MGS_HIP(hipGetLastError());
+        return 0;
+    }
     const int nb = scan_nblocks(P);
     hipLaunchKernelGGL(scan_local_kernel, dim3(nb), dim3(SCAN_THREADS), 0, s, g.tiles_touched, g.perm,
                        g.point_offsets, g.scan_blocks, P);
@@ -111,28 +140,61 @@ __global__ void __launch_bounds__(256) duplicate_kernel(int P, const float* __re
                                                         const uint32_t* __restrict__ perm,
                                                         const uint32_t* __restrict__ offsets,
                                                         const uint32_t* __restrict__ tiles_touched, uint32_t* keys,
-                                                        uint32_t* vals, int gx, int gy, uint32_t r_cap) {
+                                                        uint32_t* vals, int gx, int gy, uint32_t r_cap,
+                                                        int32_t* __restrict__ n_touched, uint2* __restrict__ ranges,
+                                                        int ntiles) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P) return;
-    const uint32_t idx = perm[i];
-    if (tiles_touched[idx] == 0) return;          // culled: its record was never written
-    uint32_t off = i == 0 ? 0u : offsets[i - 1];
-    const float4 r0 = reinterpret_cast<const float4*>(rec + (size_t)idx * REC_FLOATS)[0];
-    const float radius = rec[(size_t)idx * REC_FLOATS + R_RADIUS];
-    const float px = r0.x, py = r0.y;
-    // same expressions as preprocess (integer truncation of a float quotient)
-    const int x0 = min(gx, max(0, (int)((px - radius) / (float)TILE)));
-    const int y0 = min(gy, max(0, (int)((py - radius) / (float)TILE)));
-    const int x1 = min(gx, max(0, (int)(((px + radius) + (float)(TILE - 1)) / (float)TILE)));
-    const int y1 = min(gy, max(0, (int)(((py + radius) + (float)(TILE - 1)) / (float)TILE)));
-    for (int y = y0; y < y1; ++y)
-        for (int x = x0; x < x1; ++x) {
-            if (off < r_cap) {                       // capacity mode: never write past the buffers
-                keys[off] = (uint32_t)(y * gx + x);
-                vals[off] = idx;
+    const int lane = threadIdx.x & 63;
+    if (i < ntiles) ranges[i] = make_uint2(0u, 0u);      // empty-tile default (was a memset)
+    if (i < P) n_touched[i] = 0;                         // (was a memset)
+    uint32_t idx = 0, nt = 0, off = 0;
+    int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+    if (i < P) {
+        idx = perm[i];
+        nt = tiles_touched[idx];                         // 0: culled, its record was never written
+    }
+    if (nt) {
+        off = i == 0 ? 0u : offsets[i - 1];
+        const float4 r0 = reinterpret_cast<const float4*>(rec + (size_t)idx * REC_FLOATS)[0];
+        const float radius = rec[(size_t)idx * REC_FLOATS + R_RADIUS];
+        const float px = r0.x, py = r0.y;
+        // same expressions as preprocess (integer truncation of a float quotient)
+        x0 = min(gx, max(0, (int)((px - radius) / (float)TILE)));
+        y0 = min(gy, max(0, (int)((py - radius) / (float)TILE)));
+        x1 = min(gx, max(0, (int)(((px + radius) + (float)(TILE - 1)) / (float)TILE)));
+        y1 = min(gy, max(0, (int)(((py + radius) + (float)(TILE - 1)) / (float)TILE)));
+    }
+    // small rectangles: the owning thread walks them (y outer, x inner)
+    constexpr uint32_t BIG = 32;
+    if (nt && nt <= BIG) {
+        for (int y = y0; y < y1; ++y)
+            for (int x = x0; x < x1; ++x) {
+                if (off < r_cap) {                       // capacity mode: never write past the buffers
+                    keys[off] = (uint32_t)(y * gx + x);
+                    vals[off] = idx;
+                }
+                ++off;
             }
-            ++off;
+    }
+    // large rectangles (a Gaussian covering hundreds of tiles would serialise its thread): the whole wave
+    // emits them together, 64 consecutive instances per step, in the same (y outer, x inner) order
+    unsigned long long big = __builtin_amdgcn_ballot_w64(nt > BIG);
+    while (big) {
+        const int j = __builtin_ctzll(big);
+        big &= big - 1;
+        const uint32_t b_idx = (uint32_t)__builtin_amdgcn_readlane((int)idx, j);
+        const uint32_t b_nt = (uint32_t)__builtin_amdgcn_readlane((int)nt, j);
+        const uint32_t b_off = (uint32_t)__builtin_amdgcn_readlane((int)off, j);
+        const int b_x0 = __builtin_amdgcn_readlane(x0, j), b_y0 = __builtin_amdgcn_readlane(y0, j);
+        const int b_w = __builtin_amdgcn_readlane(x1, j) - b_x0;
+        for (uint32_t t = lane; t < b_nt; t += 64) {
+            const uint32_t o = b_off + t;
+            if (o < r_cap) {
+                keys[o] = (uint32_t)((b_y0 + (int)(t / (uint32_t)b_w)) * gx + b_x0 + (int)(t % (uint32_t)b_w));
+                vals[o] = b_idx;
+            }
         }
+    }
 }
 
 __global__ void clamp_count_kernel(const uint32_t* __restrict__ offsets, int P, uint32_t r_cap, uint32_t* count) {
@@ -153,11 +215,13 @@ int launch_clamp_count(const GeometryState& g, int P, uint64_t r_cap, uint32_t* 
 }
 
 int launch_duplicate(const mgs_camera& cam, int P, const GeometryState& g, const BinningState& b, uint64_t r_cap,
-                     hipStream_t s) {
-    if (P == 0) return 0;
-    hipLaunchKernelGGL(duplicate_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, g.rec, g.perm, g.point_offsets,
+                     int32_t* n_touched, const ImageState& img, hipStream_t s) {
+    const int ntiles = tiles_x(cam.image_width) * tiles_y(cam.image_height);
+    const int n = P > ntiles ? P : ntiles;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(duplicate_kernel, dim3((n + 255) / 256), dim3(256), 0, s, P, g.rec, g.perm, g.point_offsets,
                        g.tiles_touched, b.keys_a, b.vals_a, tiles_x(cam.image_width), tiles_y(cam.image_height),
-                       (uint32_t)(r_cap > 0xFFFFFFFFull ? 0xFFFFFFFFull : r_cap));
+                       (uint32_t)(r_cap > 0xFFFFFFFFull ? 0xFFFFFFFFull : r_cap), n_touched, img.ranges, ntiles);
     MGS_HIP(hipGetLastError());
     return 0;
 }
@@ -198,7 +262,7 @@ __global__ void __launch_bounds__(256) ranges_kernel(uint64_t R, const uint32_t*
 
 int launch_ranges(const BinningState& b, uint64_t R, const ImageState& img, int ntiles, hipStream_t s,
                   const uint32_t* n_dev) {
-    MGS_HIP(hipMemsetAsync(img.ranges, 0, (size_t)ntiles * sizeof(uint2), s));
+    (void)ntiles;        // the ranges were zeroed by duplicate_kernel
     if (R == 0) return 0;
     hipLaunchKernelGGL(ranges_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, R, n_dev, b.keys_sorted,
                        img.ranges);

@@ -113,7 +113,7 @@ int launch_scan(const GeometryState& g, int P, hipStream_t s);
 // `r_cap`: capacity of the binning buffers; `count` (device): [0] live instance count min(R, r_cap), [1] overflow flag
 int launch_clamp_count(const GeometryState& g, int P, uint64_t r_cap, uint32_t* count, hipStream_t s);
 int launch_duplicate(const mgs_camera& cam, int P, const GeometryState& g, const BinningState& b, uint64_t r_cap,
-                     hipStream_t s);
+                     int32_t* n_touched, const ImageState& img, hipStream_t s);
 size_t sort_temp_bytes(uint64_t n, int bits);
 size_t radix_temp_bytes(uint64_t n, int bits);
 bool radix_result_in_b(int bits);

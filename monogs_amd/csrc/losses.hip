@@ -12,16 +12,16 @@
 //              with m = mask * grad_mask * (opacity > 0.99); the depth term is 0 when its mask is empty
 //   rgb = exp(a) * render + b   (exposure; identity when `init`)
 //
-// One reduction kernel per forward (sums + counts, last-arriving workgroup finishes the scalar), one
-// elementwise kernel per backward.  HBM-bound: ~44 B/pixel read forward, ~60 B/pixel backward.
+// Forward: one reduction kernel (<= 64 workgroups write partial sums) + a one-wave finalize kernel that adds
+// them in a fixed order (no atomics, no memset, bitwise reproducible); backward: one elementwise kernel.  HBM-bound: ~44 B/pixel read forward, ~60 B/pixel backward.
 #include "common.h"
 
 namespace mgs {
 
 constexpr int LS_THREADS = 256;
-// partial sums kept in a 16-float device scratch
-enum : int { LP_SUM_RGB = 0, LP_CNT_RGB = 1, LP_SUM_D = 2, LP_CNT_D = 3, LP_SUM_OPAC = 4, LP_TICKET = 5,
-             LP_L1_RGB = 6, LP_L1_D = 7, LP_SCALE_RGB = 8, LP_SCALE_D = 9, LP_N = 16 };
+constexpr int LS_MAX_BLOCKS = 64;       // forward reduction: few large workgroups, two tiny stages, no atomics
+// scratch: 16 floats of results followed by LS_MAX_BLOCKS x 8 floats of per-workgroup partial sums
+enum : int { LP_L1_RGB = 6, LP_L1_D = 7, LP_SCALE_RGB = 8, LP_SCALE_D = 9, LP_N = 16, LP_PART = 8 };
 
 struct LossArgs {
     const float *render, *depth, *opacity, *gt_rgb, *gt_depth, *exp_a, *exp_b;
@@ -42,10 +42,8 @@ __device__ __forceinline__ float block_sum(float v, float* smem) {
 
 __device__ __forceinline__ float sgn(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }
 
-__global__ void __launch_bounds__(LS_THREADS) loss_forward_kernel(LossArgs a, float* __restrict__ part,
-                                                                  float* __restrict__ loss_out) {
+__global__ void __launch_bounds__(LS_THREADS) loss_forward_kernel(LossArgs a, float* __restrict__ part) {
     __shared__ float smem[4];
-    __shared__ bool is_last;
     const size_t HW = (size_t)a.W * a.H;
     const float ea = a.init ? 1.f : __expf(a.exp_a[0]), eb = a.init ? 0.f : a.exp_b[0];
     float s_rgb = 0.f, c_rgb = 0.f, s_d = 0.f, c_d = 0.f, s_op = 0.f;
@@ -78,21 +76,27 @@ __global__ void __launch_bounds__(LS_THREADS) loss_forward_kernel(LossArgs a, fl
     c_d = block_sum(c_d, smem);
     s_op = block_sum(s_op, smem);
     if (threadIdx.x == 0) {
-        atomicAdd(part + LP_SUM_RGB, s_rgb);
-        atomicAdd(part + LP_CNT_RGB, c_rgb);
-        atomicAdd(part + LP_SUM_D, s_d);
-        atomicAdd(part + LP_CNT_D, c_d);
-        atomicAdd(part + LP_SUM_OPAC, s_op);
-        __threadfence();
-        const float ticket = atomicAdd(part + LP_TICKET, 1.f);
-        is_last = ticket == (float)(gridDim.x - 1);
+        float* o = part + LP_N + (size_t)blockIdx.x * LP_PART;
+        o[0] = s_rgb; o[1] = c_rgb; o[2] = s_d; o[3] = c_d; o[4] = s_op;
     }
-    __syncthreads();
-    if (is_last && threadIdx.x == 0) {
-        // every other workgroup's adds are memory-side atomics that completed before its ticket add
-        const float S_rgb = atomicAdd(part + LP_SUM_RGB, 0.f), C_rgb = atomicAdd(part + LP_CNT_RGB, 0.f);
-        const float S_d = atomicAdd(part + LP_SUM_D, 0.f), C_d = atomicAdd(part + LP_CNT_D, 0.f);
-        const float S_op = atomicAdd(part + LP_SUM_OPAC, 0.f);
+}
+
+// one wave: sum the per-workgroup partials in a fixed order (bitwise reproducible) and finish the scalar
+__global__ void loss_finalize_kernel(LossArgs a, int nblocks, float* __restrict__ part, float* __restrict__ loss_out) {
+    const int lane = threadIdx.x;
+    float v[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    if (lane < nblocks) {
+        const float* o = part + LP_N + (size_t)lane * LP_PART;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) v[k] = o[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_xor(v[k], o, 64);
+    if (lane == 0) {
+        const size_t HW = (size_t)a.W * a.H;
+        const float S_rgb = v[0], C_rgb = v[1], S_d = v[2], C_d = v[3], S_op = v[4];
         float l1_rgb, l1_d, scale_rgb, scale_d, loss;
         if (a.tracking) {
             const float mean_op = S_op / (float)HW;
@@ -164,10 +168,15 @@ static int loss_grid(int W, int H) {
     size_t nb = (HW + LS_THREADS * 4 - 1) / (LS_THREADS * 4);
     return (int)(nb < 1 ? 1 : (nb > 1024 ? 1024 : nb));
 }
+static int loss_fwd_grid(int W, int H) {
+    const int g = loss_grid(W, H);
+    return g > LS_MAX_BLOCKS ? LS_MAX_BLOCKS : g;
+}
 
 int launch_loss_forward(const LossArgs& a, float* partials, float* loss_out, hipStream_t s) {
-    MGS_HIP(hipMemsetAsync(partials, 0, LP_N * sizeof(float), s));
-    hipLaunchKernelGGL(loss_forward_kernel, dim3(loss_grid(a.W, a.H)), dim3(LS_THREADS), 0, s, a, partials, loss_out);
+    const int nb = loss_fwd_grid(a.W, a.H);
+    hipLaunchKernelGGL(loss_forward_kernel, dim3(nb), dim3(LS_THREADS), 0, s, a, partials);
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(WAVE), 0, s, a, nb, partials, loss_out);
     MGS_HIP(hipGetLastError());
     return 0;
 }
@@ -201,7 +210,7 @@ static int fill_args(LossArgs& a, int32_t W, int32_t H, int32_t tracking, int32_
     return 0;
 }
 
-size_t mgs_loss_scratch_bytes(void) { return LP_N * sizeof(float); }
+size_t mgs_loss_scratch_bytes(void) { return (LP_N + LS_MAX_BLOCKS * LP_PART) * sizeof(float); }
 
 int mgs_loss_forward(int32_t W, int32_t H, int32_t tracking, int32_t init, float lambda_rgb, const float* render,
                      const float* depth, const float* opacity, const float* gt_rgb, const float* gt_depth,

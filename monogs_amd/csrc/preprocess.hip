@@ -560,7 +560,6 @@ int launch_geom_backward(const mgs_camera& cam, int P, const GeometryState& g, c
     a.focal_y = (float)cam.image_height / (2.0f * cam.tanfovy);
     a.mod = cam.scale_modifier;
     a.P = P; a.W = cam.image_width; a.H = cam.image_height; a.deg = cam.sh_degree; a.M = cam.sh_coeffs;
-    if (ga.dL_dtau) MGS_HIP(hipMemsetAsync(ga.dL_dtau, 0, 6 * sizeof(float), s));
     if (P == 0) return 0;
     if (ga.colors_precomp)
         hipLaunchKernelGGL(geom_backward_kernel<false>, dim3((P + 255) / 256), dim3(256), 0, s, a);

@@ -134,8 +134,11 @@ class GaussianMap:
         cat = [torch.cat([o.detach(), n], 0).requires_grad_(True) for o, n in zip(self.params(), new)]
         self._xyz, self._rgb, self._opacity, self._scaling, self._rotation = cat
         lrs = [1.6e-4 * 6.0, 0.0025, 0.05, 0.001, 0.001]   # position/feature/opacity/scaling/rotation lrs of the reference
-        self.optimizer = torch.optim.Adam([{"params": [p], "lr": lr} for p, lr in zip(self.params(), lrs)], eps=1e-15,
-                                          capturable=self.capturable)
+        groups = [{"params": [p], "lr": lr} for p, lr in zip(self.params(), lrs)]
+        try:       # one multi-tensor kernel per step (the reference uses the default, unfused Adam)
+            self.optimizer = torch.optim.Adam(groups, eps=1e-15, fused=True, capturable=self.capturable)
+        except Exception:
+            self.optimizer = torch.optim.Adam(groups, eps=1e-15, capturable=self.capturable)
         # carry Adam moments of the old Gaussians over, zeros for the new ones (densification_postfix)
         for i, p in enumerate(self.params()):
             st = old_state.get(i)

@@ -245,3 +245,83 @@ def test_capacity_mode_matches_exact_path(native_lib):
     finally:
         R.set_sync_free(False)
         R._capacity_hint.pop((20000, 640, 480), None)
+
+
+def test_streams_nograd_and_noncontiguous_inputs(native_lib):
+    """The library launches on the caller's current stream, works under no_grad, with inputs that do not
+    require grad and with non-contiguous views (made contiguous at the boundary, as upstream's .contiguous())."""
+    from monogs_amd.rasterizer import GaussianRasterizer
+    sc = make_scene(6000, "fr3_office", seed=141)
+    st = _hip_st(sc)
+    dev = lambda t: t.to(DEV)  # noqa: E731
+    args = dict(means3D=dev(sc.means3D), opacities=dev(sc.opacities), colors_precomp=dev(sc.colors),
+                scales=dev(sc.scales.repeat(1, 3)), rotations=dev(sc.rotations))
+    with torch.no_grad():
+        ref = GaussianRasterizer(st)(means2D=torch.zeros_like(args["means3D"]), **args)
+    # side stream
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s), torch.no_grad():
+        out = GaussianRasterizer(st)(means2D=torch.zeros_like(args["means3D"]), **args)
+    s.synchronize()
+    for a, b in zip(ref, out):
+        assert torch.equal(a, b)
+    # non-contiguous views of wider tensors
+    wide = torch.zeros(6000, 8, device=DEV)
+    wide[:, 1:4] = args["means3D"]
+    colw = torch.zeros(6000, 6, device=DEV)
+    colw[:, ::2] = args["colors_precomp"]
+    a2 = dict(args, means3D=wide[:, 1:4], colors_precomp=colw[:, ::2])
+    assert not a2["means3D"].is_contiguous() and not a2["colors_precomp"].is_contiguous()
+    with torch.no_grad():
+        out2 = GaussianRasterizer(st)(means2D=torch.zeros(6000, 3, device=DEV), **a2)
+    for a, b in zip(ref, out2):
+        assert torch.equal(a, b)
+    # only the pose requires grad (tracking with a frozen map): Gaussian gradients are simply not produced
+    th = torch.zeros(3, device=DEV, requires_grad=True)
+    rh = torch.zeros(3, device=DEV, requires_grad=True)
+    o3 = GaussianRasterizer(st)(means2D=torch.zeros(6000, 3, device=DEV), theta=th, rho=rh, **args)
+    (o3[0] * sc.grad_color.to(DEV)).sum().backward()
+    assert th.grad is not None and rh.grad is not None and th.grad.abs().sum() > 0
+    _, og = rasterize_autograd(dict(means3D=sc.means3D, opacities=sc.opacities, colors_precomp=sc.colors,
+                                    scales=sc.scales.repeat(1, 3), rotations=sc.rotations),
+                               scene_settings(sc, OracleSettings), sc.grad_color, torch.zeros_like(sc.grad_depth),
+                               dtype=torch.float32)
+    assert ((th.grad.cpu() - og["theta"]).norm() / og["theta"].norm()).item() < 1e-3
+    assert ((rh.grad.cpu() - og["rho"]).norm() / og["rho"].norm()).item() < 1e-3
+
+
+def test_graph_capture_of_forward_backward(native_lib):
+    """A forward + backward captured in a hipGraph (capacity mode) replays to the same gradients."""
+    from monogs_amd import rasterizer as R
+    from monogs_amd.rasterizer import GaussianRasterizer
+    sc = make_scene(8000, "fr3_office", seed=151)
+    st = _hip_st(sc)
+    m = sc.means3D.to(DEV).clone().requires_grad_(True)
+    o, c, r = sc.opacities.to(DEV), sc.colors.to(DEV), sc.rotations.to(DEV)
+    s3 = sc.scales.repeat(1, 3).to(DEV)
+    gc, gd = sc.grad_color.to(DEV), sc.grad_depth.to(DEV)
+
+    def step():
+        out = GaussianRasterizer(st)(means3D=m, means2D=torch.zeros_like(m), opacities=o, colors_precomp=c, scales=s3,
+                                     rotations=r)
+        ((out[0] * gc).sum() + (out[2] * gd).sum()).backward()
+        return out[0]
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        img_ref = step().detach().clone()        # eager: records the capacity hint
+    torch.cuda.current_stream().wait_stream(side)
+    g_ref = m.grad.clone()
+    m.grad = None
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        img = step()
+    for _ in range(3):
+        graph.replay()
+    torch.cuda.synchronize()
+    assert not R.check_overflow()
+    assert torch.equal(img, img_ref)
+    assert torch.allclose(m.grad, g_ref, rtol=1e-4, atol=1e-10)
+    R.clear_graph_flags()

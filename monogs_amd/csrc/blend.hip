@@ -120,8 +120,8 @@ __global__ void __launch_bounds__(256) blend_forward_kernel(BlendArgs a, float* 
             const uint32_t gid = bcast(gid_l, j);
             const Rec g = fetch(a, gid);
             const float dx = g.px - pxf, dy = g.py - pyf;
-            const float power = -0.5f * (g.ca * dx * dx + g.cc * dy * dy) - g.cb * dx * dy;
-            const float alpha = fminf(0.99f, g.op * __expf(power));
+            const float power = dx * (g.ca * dx + g.cb * dy) + (g.cc * dy) * dy;     // log2 of the Gaussian falloff
+            const float alpha = fminf(0.99f, g.op * __builtin_amdgcn_exp2f(power));
             const bool act = !(power > 0.f) && !(alpha < 1.0f / 255.0f);
             const float test_T = T * (1.f - alpha);
             const bool stop = act && (test_T < 0.0001f);
@@ -345,8 +345,8 @@ __global__ void __launch_bounds__(256) blend_backward_kernel(BlendArgs a, int nt
             for (int q = 0; q < NQ; ++q) {
                 if (NQ > 1 && ((qmask[q] >> j) & 1ull) == 0ull) continue;      // wave-uniform: box misses this quadrant
                 const float dx = g.px - pxf[q], dy = g.py - pyf[q];
-                const float power = -0.5f * (g.ca * dx * dx + g.cc * dy * dy) - g.cb * dx * dy;
-                const float G = __expf(power);
+                const float power = dx * (g.ca * dx + g.cb * dy) + (g.cc * dy) * dy;   // log2 of the Gaussian falloff
+                const float G = __builtin_amdgcn_exp2f(power);
                 const float alpha = fminf(0.99f, g.op * G);
                 const bool act = (k <= last[q]) && !(power > 0.f) && !(alpha < 1.0f / 255.0f);
                 if (__builtin_amdgcn_ballot_w64(act) == 0ull) continue;

@@ -17,7 +17,9 @@ constexpr int GRAD_FLOATS = 16;         // per-Gaussian gradient accumulator: on
 
 // blend record slots (float index inside the 64-byte record written by preprocess):
 //   float4 #0 {px, py, ex, ey}   what a lane needs for the quadrant cull test
-//   float4 #1 {conic a, b, c, opacity}   } fetched with scalar loads for a surviving instance
+//   float4 #1 {ka, kb, kc, opacity}      } fetched with scalar loads for a surviving instance;
+//                                          (ka, kb, kc) = (-log2e/2 a, -log2e b, -log2e/2 c) of the conic, so that
+//                                          alpha = opacity * exp2(ka dx^2 + kb dx dy + kc dy^2): 5 VALU ops + v_exp_f32
 //   float4 #2 {r, g, b, depth}           }
 //   float4 #3 {na, nb, nc, radius}   conic / (2 ln(255 o)) for the exact ellipse-vs-quadrant cull test; radius for duplicate
 enum : int {

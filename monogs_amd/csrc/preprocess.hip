@@ -235,7 +235,9 @@ __global__ void __launch_bounds__(256) preprocess_forward_kernel(PreArgs a) {
 
     float4* rec = reinterpret_cast<float4*>(a.rec + (size_t)idx * REC_FLOATS);
     rec[0] = make_float4(px, py, ex, ey);
-    rec[1] = make_float4(ca, cb, cc, opac);
+    // conic pre-scaled for the blend kernels: alpha = opacity * exp2(ka dx^2 + kc dy^2 + kb dx dy)
+    constexpr float LOG2E = 1.4426950408889634f;
+    rec[1] = make_float4(-0.5f * LOG2E * ca, -LOG2E * cb, -0.5f * LOG2E * cc, opac);
     rec[2] = make_float4(rgb[0], rgb[1], rgb[2], pv[2]);
     rec[3] = make_float4(na, nb, nc, radius);
     a.radii[idx] = (int)radius;
@@ -329,8 +331,11 @@ __global__ void __launch_bounds__(256) geom_backward_kernel(BwdArgs a) {
 
         // ---- conic -> 2-D covariance.  Q = C^-1;  dL/dC = -Q G Q with G the symmetric matrix
         //      [[gA, gB/2],[gB/2, gC]] (gB is the derivative w.r.t. the scalar b of power = -a dx^2/2 - c dy^2/2 - b dx dy)
-        const float4 r1 = reinterpret_cast<const float4*>(a.rec + (size_t)idx * REC_FLOATS)[1];
-        const float qa = r1.x, qb = r1.y, qc = r1.z, opq = r1.w;
+        // the conic, exactly as the forward computed it (same operations on the same inputs)
+        const float det_q = p.cxx * p.cyy - p.cxy * p.cxy;
+        const float det_inv_q = 1.f / det_q;
+        const float qa = p.cyy * det_inv_q, qb = -p.cxy * det_inv_q, qc = p.cxx * det_inv_q;
+        const float opq = a.g.opacities[idx];
         // raw moments -> gradients w.r.t. the conic entries and the pixel-space mean (see common.h)
         const float gA = -0.5f * opq * ga[G_SXX], gBh = 0.5f * (-opq * ga[G_SXY]), gC = -0.5f * opq * ga[G_SYY];
         // N = G Q

@@ -146,3 +146,55 @@ def test_knn(native_lib):
     pts[50:] = pts[:50]
     got = distCUDA2(pts.to(DEV)).cpu()
     assert torch.allclose(got, dist2_knn(pts), rtol=1e-5, atol=1e-9)
+
+
+def test_c5_full_size_properties(native_lib):
+    """BASELINE config 5 (2 M Gaussians, 1920x1080) is too large for the oracle, so it is checked through
+    size-independent properties: the tile lists partition [0, R) and are sorted by (tile, depth bits, index),
+    the image invariants hold, the forward is bitwise repeatable, and the backward is linear in the upstream
+    gradient."""
+    from monogs_amd.debug import forward_tables
+    from monogs_amd.rasterizer import GaussianRasterizer
+    sc = make_scene(2_000_000, "davis_1080p", seed=2)
+    st = _hip_settings(sc)
+    dev = lambda t: t.to(DEV)  # noqa: E731
+    args = dict(colors_precomp=dev(sc.colors), scales=dev(sc.scales.repeat(1, 3)), rotations=dev(sc.rotations))
+    t = forward_tables(st, dev(sc.means3D), dev(sc.opacities), **args)
+    R = t["num_rendered"]
+    assert R == int(t["tiles_touched"].long().sum())
+    rg = t["ranges"].long()
+    ne = rg[rg[:, 1] > rg[:, 0]]
+    assert ne[0, 0] == 0 and ne[-1, 1] == R and bool((ne[1:, 0] == ne[:-1, 1]).all())
+    # sortedness: (tile, depth bits, Gaussian index) strictly increasing along the instance list
+    tile = t["tile_sorted"].long()
+    pl = t["point_list"].long()
+    depth = (t["depth_key"].long() & 0xFFFFFFFF)[pl]
+    key = (tile << 32) | depth
+    d = key[1:] - key[:-1]
+    assert bool((d >= 0).all())
+    same = d == 0
+    assert bool((pl[1:][same] > pl[:-1][same]).all())
+    # every instance sits in the tile its range says
+    starts = torch.repeat_interleave(torch.arange(rg.shape[0], device=DEV), (rg[:, 1] - rg[:, 0]))
+    assert torch.equal(starts, tile)
+    # image invariants
+    assert torch.allclose(t["opacity"][0], 1 - t["final_T"], atol=1e-6)
+    assert bool(((t["n_touched"] > 0) <= (t["radii"] > 0)).all())
+    assert bool((t["n_contrib"].long() <= (rg[:, 1] - rg[:, 0]).max()).all())
+    assert bool(torch.isfinite(t["color"]).all()) and float(t["opacity"].max()) <= 1.0
+    # forward is bitwise repeatable (no atomics on the pixel path)
+    t2 = forward_tables(st, dev(sc.means3D), dev(sc.opacities), **args)
+    assert torch.equal(t["color"], t2["color"]) and torch.equal(t["point_list"], t2["point_list"])
+    assert torch.equal(t["n_touched"], t2["n_touched"])
+    # backward: linear in the upstream gradient
+    def grads(scale):
+        m = dev(sc.means3D).clone().requires_grad_(True)
+        th = torch.zeros(3, device=DEV, requires_grad=True)
+        out = GaussianRasterizer(st)(means3D=m, means2D=torch.zeros_like(m), opacities=dev(sc.opacities), theta=th,
+                                     rho=torch.zeros(3, device=DEV, requires_grad=True), **args)
+        ((out[0] * dev(sc.grad_color)).sum() * scale + (out[2] * dev(sc.grad_depth)).sum() * scale).backward()
+        return m.grad, th.grad
+    g1, t1 = grads(1.0)
+    g3, t3 = grads(3.0)
+    assert ((g3 - 3 * g1).norm() / (3 * g1).norm()).item() < 1e-5
+    assert ((t3 - 3 * t1).norm() / (3 * t1).norm()).item() < 1e-4

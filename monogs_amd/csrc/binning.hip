@@ -90,37 +90,8 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_add_kernel(uint32_t* out, c
         if (base + i < n) out[base + i] += add;
 }
 
-// One workgroup, one launch: enough for SLAM-sized maps (three launches cost more than the scan itself)
-constexpr int SCAN_SMALL_THREADS = 1024;
-constexpr int SCAN_SMALL_MAX = SCAN_SMALL_THREADS * 64;
-__global__ void __launch_bounds__(SCAN_SMALL_THREADS) scan_small_kernel(const uint32_t* __restrict__ in,
-                                                                        const uint32_t* __restrict__ perm,
-                                                                        uint32_t* __restrict__ out, int n) {
-    __shared__ uint32_t wsum[SCAN_SMALL_THREADS / 64];
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    const int per = (n + SCAN_SMALL_THREADS - 1) / SCAN_SMALL_THREADS;
-    const int b = t * per, e = min(n, b + per);
-    uint32_t sum = 0;
-    for (int i = b; i < e; ++i) sum += in[perm[i]];
-    const uint32_t incl = wave_incl_scan(sum, lane);
-    if (lane == 63) wsum[wv] = incl;
-    __syncthreads();
-    uint32_t run = incl - sum;
-    for (int w = 0; w < wv; ++w) run += wsum[w];
-    for (int i = b; i < e; ++i) {
-        run += in[perm[i]];
-        out[i] = run;
-    }
-}
-
 int launch_scan(const GeometryState& g, int P, hipStream_t s) {
     if (P == 0) return 0;
-    if (P <= SCAN_SMALL_MAX) {
-        hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(SCAN_SMALL_THREADS), 0, s, g.tiles_touched, g.perm,
-                           g.point_offsets, P);
-        MGS_HIP(hipGetLastError());
-        return 0;
-    }
     const int nb = scan_nblocks(P);
     hipLaunchKernelGGL(scan_local_kernel, dim3(nb), dim3(SCAN_THREADS), 0, s, g.tiles_touched, g.perm,
                        g.point_offsets, g.scan_blocks, P);

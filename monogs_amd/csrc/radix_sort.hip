@@ -5,8 +5,8 @@
 // (SURVEY.md section 2.1 K4).
 //
 // Structure ("one sweep" per 8-bit digit):
-//   * ONE histogram kernel reads the keys once and counts every digit of every pass; a tiny kernel
-//     turns the counts into exclusive global bases;
+//   * ONE histogram kernel reads the keys once and counts every digit of every pass (each pass kernel
+//     scans its 256 counts into exclusive global bases itself);
 //   * per pass ONE kernel.  A workgroup (256 threads = 4 waves) takes a tile of 4096 pairs, ranks
 //     them stably (wave64 __ballot match per digit bit + per-wave LDS counters), publishes its 256
 //     digit counts, obtains the sum of the counts of all EARLIER tiles by decoupled look-back, lays
@@ -92,24 +92,6 @@ __global__ void __launch_bounds__(RS_THREADS) rs_hist_kernel(const uint32_t* __r
     }
 }
 
-// one workgroup per pass: exclusive scan of its 256 bins
-__global__ void __launch_bounds__(RS_RADIX) rs_scan_kernel(const uint32_t* __restrict__ hist, uint32_t* __restrict__ base) {
-    __shared__ uint32_t wsum[RS_RADIX / WAVE];
-    const int p = blockIdx.x, d = threadIdx.x, lane = d & 63, wv = d >> 6;
-    const uint32_t c = hist[p * RS_RADIX + d];
-    uint32_t v = c;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t u = __shfl_up(v, o, 64);
-        if (lane >= o) v += u;
-    }
-    if (lane == 63) wsum[wv] = v;
-    __syncthreads();
-    uint32_t add = 0;
-    for (int w = 0; w < wv; ++w) add += wsum[w];
-    base[p * RS_RADIX + d] = add + v - c;
-}
-
 struct RsPassArgs {
     const uint32_t* kin;
     uint32_t* kout;
@@ -118,7 +100,7 @@ struct RsPassArgs {
     uint32_t n;               // number of pairs (capacity when n_dev is set)
     const uint32_t* n_dev;    // optional: live count on the device (<= n after clamping)
     int shift;
-    const uint32_t* base;     // [256] exclusive global base of each digit for this pass
+    const uint32_t* hist;     // [256] global count of each digit for this pass
     uint64_t* status;         // [tiles][256]
     uint32_t* ticket;
     uint32_t* error;
@@ -199,6 +181,21 @@ __global__ void __launch_bounds__(RS_THREADS) rs_pass_kernel(RsPassArgs a) {
     for (int w = 0; w < wv; ++w) wadd += wsum[w];
     const uint32_t dbase = wadd + incl - total;
     digit_base[t] = dbase;
+    // exclusive global base of digit t = scan of this pass's global histogram (256 values: cheaper here
+    // than a separate launch between the histogram and the first pass)
+    const uint32_t hcount = a.hist[t];
+    uint32_t hincl = hcount;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t u = __shfl_up(hincl, o, 64);
+        if (lane >= o) hincl += u;
+    }
+    __syncthreads();                     // wsum is reused
+    if (lane == 63) wsum[wv] = hincl;
+    __syncthreads();
+    uint32_t hadd = 0;
+    for (int w = 0; w < wv; ++w) hadd += wsum[w];
+    const uint32_t gdigit_base = hadd + hincl - hcount;
 
     // ---- publish, look back, publish (one digit per thread)
     uint64_t* my = a.status + (size_t)tile * RS_RADIX + t;
@@ -246,7 +243,7 @@ __global__ void __launch_bounds__(RS_THREADS) rs_pass_kernel(RsPassArgs a) {
         __hip_atomic_store(my, RS_FLAG_GLOBAL | (prefix + (uint64_t)total), __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
     }
-    gbase[t] = (int64_t)a.base[t] + (int64_t)prefix - (int64_t)dbase;
+    gbase[t] = (int64_t)gdigit_base + (int64_t)prefix - (int64_t)dbase;
     __syncthreads();
 
     // ---- lay the tile out digit by digit in LDS (stable), then stream each run to its final place
@@ -294,13 +291,12 @@ int radix_sort_pairs(uint32_t* ka, uint32_t* va, uint32_t* kb, uint32_t* vb, uin
     const uint32_t tiles = rs_tiles(n);
     const uint32_t hist_blocks = min(tiles, 1024u);
     hipLaunchKernelGGL(rs_hist_kernel, dim3(hist_blocks), dim3(RS_THREADS), 0, s, ka, (uint32_t)n, n_dev, npasses, t.hist);
-    hipLaunchKernelGGL(rs_scan_kernel, dim3(npasses), dim3(RS_RADIX), 0, s, t.hist, t.base);
     uint32_t *kin = ka, *vin = va, *kout = kb, *vout = vb;
     for (int p = 0; p < npasses; ++p) {
         RsPassArgs a;
         a.kin = kin; a.kout = kout; a.vin = vin; a.vout = vout;
         a.n = (uint32_t)n; a.n_dev = n_dev; a.shift = 8 * p;
-        a.base = t.base + p * RS_RADIX;
+        a.hist = t.hist + p * RS_RADIX;
         a.status = t.status + (size_t)p * tiles * RS_RADIX;
         a.ticket = t.tickets + p;
         a.error = t.error;

@@ -24,8 +24,10 @@ namespace mgs {
 
 constexpr int RS_THREADS = 256;
 constexpr int RS_WAVES = RS_THREADS / WAVE;
-constexpr int RS_ITEMS = 16;
-constexpr int RS_TILE = RS_THREADS * RS_ITEMS;     // 4096 pairs per workgroup
+constexpr int RS_ITEMS = 16;                       // pairs per thread for large sorts: 4096-pair tiles
+constexpr int RS_ITEMS_SMALL = 4;                  // small sorts are latency-bound: 1024-pair tiles rank 4x faster
+constexpr uint64_t RS_SMALL_MAX = 256 * 1024;      // <= 256 small tiles (one per CU)
+static inline int rs_items(uint64_t n) { return n <= RS_SMALL_MAX ? RS_ITEMS_SMALL : RS_ITEMS; }
 constexpr int RS_RADIX = 256;
 constexpr int RS_MAX_PASSES = 4;
 constexpr uint64_t RS_FLAG_LOCAL = 1ull << 62;     // count of this tile only
@@ -35,7 +37,10 @@ constexpr uint32_t RS_SPIN_LIMIT = 1u << 22;
 constexpr int RS_WINDOW = 16;                     // predecessor status words fetched per look-back step
 
 static inline int rs_passes(int bits) { return (bits + 7) / 8; }
-static inline uint32_t rs_tiles(uint64_t n) { return (uint32_t)((n + RS_TILE - 1) / RS_TILE); }
+static inline uint32_t rs_tiles(uint64_t n) {
+    const uint64_t tile = (uint64_t)RS_THREADS * rs_items(n);
+    return (uint32_t)((n + tile - 1) / tile);
+}
 
 // temp layout: [hist: RS_MAX_PASSES*256 u32][base: RS_MAX_PASSES*256 u32][tickets: RS_MAX_PASSES u32]
 //              [error: 1 u32][pad][status: passes * tiles * 256 u64]
@@ -106,39 +111,41 @@ struct RsPassArgs {
     uint32_t* error;
 };
 
+template <int ITEMS>
 __global__ void __launch_bounds__(RS_THREADS) rs_pass_kernel(RsPassArgs a) {
+    constexpr int TILE_PAIRS = RS_THREADS * ITEMS;
     __shared__ uint32_t wave_hist[RS_WAVES][RS_RADIX];
     __shared__ uint32_t digit_base[RS_RADIX];
     __shared__ int64_t gbase[RS_RADIX];                  // global position of LDS slot 0 for each digit (may be negative)
-    __shared__ uint32_t skeys[RS_TILE];
-    __shared__ uint32_t svals[RS_TILE];
+    __shared__ uint32_t skeys[TILE_PAIRS];
+    __shared__ uint32_t svals[TILE_PAIRS];
     __shared__ uint32_t wsum[RS_WAVES];
     __shared__ uint32_t s_tile;
 
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    if (t == 0) s_tile = atomicAdd(a.ticket, 1u);
+    if (t == 0) s_tile = a.ticket ? atomicAdd(a.ticket, 1u) : blockIdx.x;   // a returning atomic is a ~2 us round trip
     for (int i = t; i < RS_WAVES * RS_RADIX; i += RS_THREADS) (&wave_hist[0][0])[i] = 0;
     __syncthreads();
     const uint32_t tile = s_tile;
-    const uint32_t tile_start = tile * (uint32_t)RS_TILE;
+    const uint32_t tile_start = tile * (uint32_t)TILE_PAIRS;
     const uint32_t n_live = a.n_dev ? min(a.n, a.n_dev[0]) : a.n;
     if (tile_start >= n_live) return;        // capacity mode: tiles past the live count have nothing to do
                                              // (tickets are dense, so no live tile ever looks back at them)
-    const uint32_t tile_n = min((uint32_t)RS_TILE, n_live - tile_start);
+    const uint32_t tile_n = min((uint32_t)TILE_PAIRS, n_live - tile_start);
 
-    // ---- load (wave-striped: item i of lane l of wave w is element w*1024 + i*64 + l of the tile) and rank
-    uint32_t key[RS_ITEMS], val[RS_ITEMS], rank[RS_ITEMS];
+    // ---- load (wave-striped: item i of lane l of wave w is element w*(ITEMS*64) + i*64 + l of the tile) and rank
+    uint32_t key[ITEMS], val[ITEMS], rank[ITEMS];
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 #pragma unroll
-    for (int i = 0; i < RS_ITEMS; ++i) {
-        const uint32_t e = (uint32_t)wv * (RS_ITEMS * WAVE) + (uint32_t)i * WAVE + lane;
+    for (int i = 0; i < ITEMS; ++i) {
+        const uint32_t e = (uint32_t)wv * (ITEMS * WAVE) + (uint32_t)i * WAVE + lane;
         const bool valid = e < tile_n;
         key[i] = valid ? a.kin[tile_start + e] : 0xFFFFFFFFu;
         val[i] = valid ? a.vin[tile_start + e] : 0u;
     }
 #pragma unroll
-    for (int i = 0; i < RS_ITEMS; ++i) {
-        const uint32_t e = (uint32_t)wv * (RS_ITEMS * WAVE) + (uint32_t)i * WAVE + lane;
+    for (int i = 0; i < ITEMS; ++i) {
+        const uint32_t e = (uint32_t)wv * (ITEMS * WAVE) + (uint32_t)i * WAVE + lane;
         const bool valid = e < tile_n;
         const uint32_t d = (key[i] >> a.shift) & 0xFFu;
         unsigned long long peers = __builtin_amdgcn_ballot_w64(valid);
@@ -248,8 +255,8 @@ __global__ void __launch_bounds__(RS_THREADS) rs_pass_kernel(RsPassArgs a) {
 
     // ---- lay the tile out digit by digit in LDS (stable), then stream each run to its final place
 #pragma unroll
-    for (int i = 0; i < RS_ITEMS; ++i) {
-        const uint32_t e = (uint32_t)wv * (RS_ITEMS * WAVE) + (uint32_t)i * WAVE + lane;
+    for (int i = 0; i < ITEMS; ++i) {
+        const uint32_t e = (uint32_t)wv * (ITEMS * WAVE) + (uint32_t)i * WAVE + lane;
         if (e < tile_n) {
             const uint32_t d = (key[i] >> a.shift) & 0xFFu;
             const uint32_t pos = digit_base[d] + wave_hist[wv][d] + rank[i];
@@ -259,7 +266,7 @@ __global__ void __launch_bounds__(RS_THREADS) rs_pass_kernel(RsPassArgs a) {
     }
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < RS_ITEMS; ++i) {
+    for (int i = 0; i < ITEMS; ++i) {
         const uint32_t p = (uint32_t)i * RS_THREADS + t;
         if (p < tile_n) {
             const uint32_t k = skeys[p];
@@ -298,9 +305,13 @@ int radix_sort_pairs(uint32_t* ka, uint32_t* va, uint32_t* kb, uint32_t* vb, uin
         a.n = (uint32_t)n; a.n_dev = n_dev; a.shift = 8 * p;
         a.hist = t.hist + p * RS_RADIX;
         a.status = t.status + (size_t)p * tiles * RS_RADIX;
-        a.ticket = t.tickets + p;
+        // <= one workgroup per CU: the whole grid is co-resident whatever the dispatch order, so block ids are safe
+        a.ticket = tiles <= 256u ? nullptr : t.tickets + p;
         a.error = t.error;
-        hipLaunchKernelGGL(rs_pass_kernel, dim3(tiles), dim3(RS_THREADS), 0, s, a);
+        if (rs_items(n) == RS_ITEMS_SMALL)
+            hipLaunchKernelGGL(rs_pass_kernel<RS_ITEMS_SMALL>, dim3(tiles), dim3(RS_THREADS), 0, s, a);
+        else
+            hipLaunchKernelGGL(rs_pass_kernel<RS_ITEMS>, dim3(tiles), dim3(RS_THREADS), 0, s, a);
         uint32_t* tk = kin; kin = kout; kout = tk;
         uint32_t* tv = vin; vin = vout; vout = tv;
     }

@@ -25,9 +25,14 @@ namespace mgs {
 constexpr int RS_THREADS = 256;
 constexpr int RS_WAVES = RS_THREADS / WAVE;
 constexpr int RS_ITEMS = 16;                       // pairs per thread for large sorts: 4096-pair tiles
+constexpr int RS_ITEMS_MID = 8;
 constexpr int RS_ITEMS_SMALL = 4;                  // small sorts are latency-bound: 1024-pair tiles rank 4x faster
-constexpr uint64_t RS_SMALL_MAX = 256 * 1024;      // <= 256 small tiles (one per CU)
-static inline int rs_items(uint64_t n) { return n <= RS_SMALL_MAX ? RS_ITEMS_SMALL : RS_ITEMS; }
+// Measured on MI355X (depth sort of P keys): 40 k: 72 us (16) -> 50 us (4); 400 k: 122 us (32) / 83 us (8);
+// 400 k: 108 us (4); 2 M: 158 us (16) / 208 us (8) / 152 us (32).  A few hundred tiles is the sweet spot between the per-tile
+// ranking latency and the length of the look-back chain.
+static inline int rs_items(uint64_t n) {
+    return n <= 192ull * 1024 ? RS_ITEMS_SMALL : (n <= 1024ull * 1024 ? RS_ITEMS_MID : RS_ITEMS);
+}
 constexpr int RS_RADIX = 256;
 constexpr int RS_MAX_PASSES = 4;
 constexpr uint64_t RS_FLAG_LOCAL = 1ull << 62;     // count of this tile only
@@ -310,6 +315,8 @@ int radix_sort_pairs(uint32_t* ka, uint32_t* va, uint32_t* kb, uint32_t* vb, uin
         a.error = t.error;
         if (rs_items(n) == RS_ITEMS_SMALL)
             hipLaunchKernelGGL(rs_pass_kernel<RS_ITEMS_SMALL>, dim3(tiles), dim3(RS_THREADS), 0, s, a);
+        else if (rs_items(n) == RS_ITEMS_MID)
+            hipLaunchKernelGGL(rs_pass_kernel<RS_ITEMS_MID>, dim3(tiles), dim3(RS_THREADS), 0, s, a);
         else
             hipLaunchKernelGGL(rs_pass_kernel<RS_ITEMS>, dim3(tiles), dim3(RS_THREADS), 0, s, a);
         uint32_t* tk = kin; kin = kout; kout = tk;

@@ -166,11 +166,13 @@ def main():
     # ---- per-kernel time, live, with HIP events on the launch stream (separate from the timed region)
     roof = None
     stages = {}
+    # every rank runs the same profile steps (they contain the collective); only rank 0 records stage times
+    import contextlib
+    with (collect_timing() if rank == 0 else contextlib.nullcontext([])) as sink:
+        for _ in range(max(1, args.profile_steps)):
+            step()
+        torch.cuda.synchronize()
     if rank == 0:
-        with collect_timing() as sink:
-            for _ in range(max(1, args.profile_steps)):
-                step()
-            torch.cuda.synchronize()
         fw = [d for d in sink if d["kind"] == "forward"]
         bw = [d for d in sink if d["kind"] == "backward"]
         avg = lambda rows, k: sum(r[k] for r in rows) / max(1, len(rows))  # noqa: E731

@@ -50,7 +50,8 @@ __device__ __forceinline__ bool quadrant_hit(const float4 c /* px, py, ex, ey */
     if (!((c.z >= x0) && (-c.z <= x1) && (c.w >= y0) && (-c.w <= y1))) return false;   // bounding boxes apart
     if (x0 <= 0.f && x1 >= 0.f && y0 <= 0.f && y1 >= 0.f) return true;                 // centre inside
     if (!(n.x > 0.f) || !(n.z > 0.f)) return true;                                     // no ellipse data: keep
-    const float rby = -n.y / n.z, rbx = -n.y / n.x;
+    // v_rcp_f32 (1 ulp) instead of two IEEE divide sequences: the 2 % threshold margin dwarfs the error
+    const float rby = -n.y * __builtin_amdgcn_rcpf(n.z), rbx = -n.y * __builtin_amdgcn_rcpf(n.x);
     auto edge_x = [&](float xe) {          // x = xe, y in [y0, y1]
         const float t = fminf(y1, fmaxf(y0, rby * xe));
         return n.x * xe * xe + 2.f * n.y * xe * t + n.z * t * t;

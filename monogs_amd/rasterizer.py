@@ -167,6 +167,8 @@ class _RasterizeGaussians(torch.autograd.Function):
                     depth.data_ptr(), opacity.data_ptr(), n_touched.data_ptr(), overflow.data_ptr(), tref, _stream()),
                     "mgs_forward_render_capacity")
                 (_graph_overflow if capturing else _pending_overflow).append((key, overflow))
+                if len(_pending_overflow) > 4096:          # nobody is checking: keep the list bounded
+                    del _pending_overflow[:2048]
                 ctx.overflow = overflow
             else:
                 num_rendered = C.c_uint64(0)

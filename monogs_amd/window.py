@@ -87,9 +87,18 @@ class GradBucket:
         if not (dist.is_available() and dist.is_initialized()):
             return None
         if self.per_tensor:
-            works = [dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=group, async_op=True) for p in self.params]
-            if self.extra_cols:
-                works.append(dist.all_reduce(self.buf, op=dist.ReduceOp.SUM, group=group, async_op=True))
+            tensors = [p.grad for p in self.params] + ([self.buf] if self.extra_cols else [])
+            works = None
+            if dist.get_backend(group) == "nccl" and hasattr(dist, "_coalescing_manager"):
+                try:    # one RCCL group launch for all tensors (ncclGroupStart/End), no packing copies
+                    with dist._coalescing_manager(group, device=tensors[0].device, async_ops=True) as cm:
+                        for t in tensors:
+                            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+                    works = [cm]
+                except Exception:
+                    works = None
+            if works is None:
+                works = [dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True) for t in tensors]
             if async_op:
                 return works
             for w in works:

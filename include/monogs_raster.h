@@ -184,6 +184,21 @@ int mgs_pose_step(float* R, float* T, float* rot_delta, float* trans_delta, floa
                   float beta1, float beta2, float eps, float converged_threshold, int32_t* step_counter, float* out,
                   void* stream);
 
+/* ---- Fused Gaussian optimiser step + densification statistics ---------------
+ * mgs_adam_step: torch.optim.Adam defaults over n_tensors <= 8 float tensors in one launch (the reference's five
+ * groups: /root/reference/gaussian_splatting/scene/gaussian_model.py:398-442).  All tables are HOST arrays of
+ * device pointers / sizes / learning rates; grads[t] may be NULL (zero gradient).  `step` is the 1-based step, or
+ * step_counter (device int32) is incremented on the device and used instead (hipGraph-capturable).
+ * mgs_densify_stats: for the Gaussians with radii > 0,  xyz_gradient_accum += ||viewspace_grad[:, :2]||,
+ * denom += 1 (gaussian_model.py:888-892), max_radii_2d = max(max_radii_2d, radii) (utils/slam_mapper.py:453-457);
+ * any of the three outputs may be NULL. */
+int mgs_adam_step(int32_t n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
+                  float* const* exp_avg_sq, const uint64_t* numel, const float* lr, float beta1, float beta2,
+                  float eps, int32_t step, int32_t* step_counter, void* stream);
+int mgs_densify_stats(int32_t P, const float* viewspace_grad /* [P,3] */, const int32_t* radii,
+                      float* xyz_gradient_accum /* [P] */, float* denom /* [P] */, float* max_radii_2d /* [P] */,
+                      void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -28,6 +28,7 @@ from . import camera as cam
 from .knn import distCUDA2
 from .renderer import render
 from . import fused_losses, slam_losses
+from .gaussian_optim import GaussianAdam
 from .pose_optim import PoseAdam
 from .synthetic import make_scene
 
@@ -89,9 +90,10 @@ class GaussianMap:
     """Isotropic RGB map with the reference's activations
     (/root/reference/gaussian_splatting/scene/gaussian_model.py:84-106)."""
 
-    def __init__(self, device, capturable=False):
+    def __init__(self, device, capturable=False, fused_adam=True):
         self.device = device
         self.capturable = capturable        # torch.optim.Adam(capturable=True): step counters on the device (hipGraph)
+        self.fused_adam = fused_adam        # monogs_amd.gaussian_optim.GaussianAdam (one launch, always capturable)
         e = lambda *s: torch.empty(*s, device=device)  # noqa: E731
         self._xyz, self._rgb, self._opacity, self._scaling, self._rotation = e(0, 3), e(0, 3), e(0, 1), e(0, 1), e(0, 4)
         self.optimizer: Optional[torch.optim.Optimizer] = None
@@ -130,10 +132,20 @@ class GaussianMap:
         rots[:, 0] = 1
         opac = torch.zeros(idx.numel(), 1, device=self.device)      # inverse_sigmoid(0.5)
         new = [pw, rgb, opac, scales, rots]
-        old_state = self.optimizer.state_dict()["state"] if self.optimizer is not None else {}
+        old_opt = self.optimizer
+        old_state = old_opt.state_dict()["state"] if (old_opt is not None and not self.fused_adam) else {}
         cat = [torch.cat([o.detach(), n], 0).requires_grad_(True) for o, n in zip(self.params(), new)]
         self._xyz, self._rgb, self._opacity, self._scaling, self._rotation = cat
         lrs = [1.6e-4 * 6.0, 0.0025, 0.05, 0.001, 0.001]   # position/feature/opacity/scaling/rotation lrs of the reference
+        if self.fused_adam:
+            self.optimizer = GaussianAdam(self.params(), lrs, eps=1e-15)
+            if old_opt is not None:      # carry the moments of the old Gaussians over, zeros for the new ones
+                for i in range(5):
+                    n_old = old_opt.exp_avg[i].shape[0]
+                    self.optimizer.exp_avg[i][:n_old] = old_opt.exp_avg[i]
+                    self.optimizer.exp_avg_sq[i][:n_old] = old_opt.exp_avg_sq[i]
+                self.optimizer.t_dev.copy_(old_opt.t_dev)
+            return idx.numel()
         groups = [{"params": [p], "lr": lr} for p, lr in zip(self.params(), lrs)]
         try:       # one multi-tensor kernel per step (the reference uses the default, unfused Adam)
             self.optimizer = torch.optim.Adam(groups, eps=1e-15, fused=True, capturable=self.capturable)

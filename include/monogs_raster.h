@@ -199,6 +199,19 @@ int mgs_densify_stats(int32_t P, const float* viewspace_grad /* [P,3] */, const 
                       float* xyz_gradient_accum /* [P] */, float* denom /* [P] */, float* max_radii_2d /* [P] */,
                       void* stream);
 
+/* ---- Fused map activations ------------------------------------------------
+ * rotations = F.normalize(rot_raw), scales3 = exp(scale_raw) (isotropic [P,1] expanded to [P,3] as render() does),
+ * opacities = sigmoid(opacity_raw): /root/reference/gaussian_splatting/scene/gaussian_model.py:84-106 and
+ * gaussian_renderer/__init__.py:101-104.  One launch forward, one backward (any gradient / output may be NULL). */
+int mgs_activate_forward(int32_t P, int32_t scale_dim /* 1 or 3 */, const float* rot_raw /* [P,4] */,
+                         const float* scale_raw /* [P,scale_dim] */, const float* opacity_raw /* [P] */,
+                         float* rotations /* [P,4] */, float* scales3 /* [P,3] */, float* opacities /* [P] */,
+                         void* stream);
+int mgs_activate_backward(int32_t P, int32_t scale_dim, const float* rot_raw, const float* scales3,
+                          const float* opacities, const float* grad_rotations, const float* grad_scales3,
+                          const float* grad_opacities, float* d_rot_raw, float* d_scale_raw, float* d_opacity_raw,
+                          void* stream);
+
 #ifdef __cplusplus
 }
 #endif

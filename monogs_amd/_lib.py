@@ -60,6 +60,8 @@ SIGNATURES = {
     "mgs_pose_step": (C.c_int, [C.c_void_p] * 12 + [C.c_int32] + [C.c_float] * 7 + [C.c_void_p, C.c_void_p, C.c_void_p]),
     "mgs_adam_step": (C.c_int, [C.c_int32] + [C.c_void_p] * 6 + [C.c_float] * 3 + [C.c_int32, C.c_void_p, C.c_void_p]),
     "mgs_densify_stats": (C.c_int, [C.c_int32] + [C.c_void_p] * 6),
+    "mgs_activate_forward": (C.c_int, [C.c_int32, C.c_int32] + [C.c_void_p] * 7),
+    "mgs_activate_backward": (C.c_int, [C.c_int32, C.c_int32] + [C.c_void_p] * 10),
     "mgs_knn_scratch_bytes": (C.c_size_t, [C.c_int32]),
     "mgs_dist2_knn": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
 }

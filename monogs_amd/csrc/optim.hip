@@ -111,3 +111,107 @@ int mgs_densify_stats(int32_t P, const float* viewspace_grad, const int32_t* rad
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// Fused activations of the map: what GaussianModel.get_rotation / get_scaling /
+// get_opacity compute with F.normalize / exp / sigmoid (/root/reference/gaussian_splatting/scene/
+// gaussian_model.py:84-106) plus the isotropic scale expansion of render()
+// (/root/reference/gaussian_splatting/gaussian_renderer/__init__.py:101-104), forward and backward, one launch each.
+// ------------------------------------------------------------------------------------------------
+namespace mgs {
+
+__global__ void __launch_bounds__(256) activate_forward_kernel(int P, int scale_dim, const float* __restrict__ rot_raw,
+                                                               const float* __restrict__ scale_raw,
+                                                               const float* __restrict__ opac_raw,
+                                                               float* __restrict__ rot, float* __restrict__ scales3,
+                                                               float* __restrict__ opac) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const float4 q = reinterpret_cast<const float4*>(rot_raw)[i];
+    const float n = fmaxf(sqrtf((q.x * q.x + q.y * q.y) + (q.z * q.z + q.w * q.w)), 1e-12f);   // F.normalize eps
+    const float inv = 1.f / n;
+    reinterpret_cast<float4*>(rot)[i] = make_float4(q.x * inv, q.y * inv, q.z * inv, q.w * inv);
+    if (scale_dim == 1) {
+        const float s = expf(scale_raw[i]);
+        scales3[3 * i] = s; scales3[3 * i + 1] = s; scales3[3 * i + 2] = s;
+    } else {
+        scales3[3 * i] = expf(scale_raw[3 * i]);
+        scales3[3 * i + 1] = expf(scale_raw[3 * i + 1]);
+        scales3[3 * i + 2] = expf(scale_raw[3 * i + 2]);
+    }
+    opac[i] = 1.f / (1.f + expf(-opac_raw[i]));
+}
+
+__global__ void __launch_bounds__(256) activate_backward_kernel(int P, int scale_dim, const float* __restrict__ rot_raw,
+                                                                const float* __restrict__ scales3,
+                                                                const float* __restrict__ opac,
+                                                                const float* __restrict__ g_rot,
+                                                                const float* __restrict__ g_scales3,
+                                                                const float* __restrict__ g_opac,
+                                                                float* __restrict__ d_rot_raw,
+                                                                float* __restrict__ d_scale_raw,
+                                                                float* __restrict__ d_opac_raw) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    if (d_rot_raw) {
+        const float4 q = reinterpret_cast<const float4*>(rot_raw)[i];
+        const float4 g = g_rot ? reinterpret_cast<const float4*>(g_rot)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float n = sqrtf((q.x * q.x + q.y * q.y) + (q.z * q.z + q.w * q.w));
+        float4 o;
+        if (n > 1e-12f) {                 // d(q/|q|) = (g - u (u.g)) / |q|
+            const float inv = 1.f / n;
+            const float ux = q.x * inv, uy = q.y * inv, uz = q.z * inv, uw = q.w * inv;
+            const float ug = (ux * g.x + uy * g.y) + (uz * g.z + uw * g.w);
+            o = make_float4((g.x - ux * ug) * inv, (g.y - uy * ug) * inv, (g.z - uz * ug) * inv, (g.w - uw * ug) * inv);
+        } else {                          // clamped denominator: y = q / eps
+            o = make_float4(g.x * 1e12f, g.y * 1e12f, g.z * 1e12f, g.w * 1e12f);
+        }
+        reinterpret_cast<float4*>(d_rot_raw)[i] = o;
+    }
+    if (d_scale_raw) {
+        const float gx = g_scales3 ? g_scales3[3 * i] : 0.f, gy = g_scales3 ? g_scales3[3 * i + 1] : 0.f;
+        const float gz = g_scales3 ? g_scales3[3 * i + 2] : 0.f;
+        if (scale_dim == 1) {
+            d_scale_raw[i] = scales3[3 * i] * ((gx + gy) + gz);
+        } else {
+            d_scale_raw[3 * i] = scales3[3 * i] * gx;
+            d_scale_raw[3 * i + 1] = scales3[3 * i + 1] * gy;
+            d_scale_raw[3 * i + 2] = scales3[3 * i + 2] * gz;
+        }
+    }
+    if (d_opac_raw) {
+        const float s = opac[i];
+        d_opac_raw[i] = (g_opac ? g_opac[i] : 0.f) * s * (1.f - s);
+    }
+}
+
+}  // namespace mgs
+
+extern "C" {
+
+int mgs_activate_forward(int32_t P, int32_t scale_dim, const float* rot_raw, const float* scale_raw,
+                         const float* opacity_raw, float* rotations, float* scales3, float* opacities, void* stream) {
+    if (P < 0 || (scale_dim != 1 && scale_dim != 3)) { mgs::set_error("mgs_activate_forward: bad P / scale_dim"); return 1; }
+    if (P == 0) return 0;
+    if (!rot_raw || !scale_raw || !opacity_raw || !rotations || !scales3 || !opacities) { mgs::set_error("NULL tensor"); return 1; }
+    hipLaunchKernelGGL(mgs::activate_forward_kernel, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, P, scale_dim,
+                       rot_raw, scale_raw, opacity_raw, rotations, scales3, opacities);
+    MGS_HIP(hipGetLastError());
+    return 0;
+}
+
+int mgs_activate_backward(int32_t P, int32_t scale_dim, const float* rot_raw, const float* scales3,
+                          const float* opacities, const float* grad_rotations, const float* grad_scales3,
+                          const float* grad_opacities, float* d_rot_raw, float* d_scale_raw, float* d_opacity_raw,
+                          void* stream) {
+    if (P < 0 || (scale_dim != 1 && scale_dim != 3)) { mgs::set_error("mgs_activate_backward: bad P / scale_dim"); return 1; }
+    if (P == 0) return 0;
+    if (!rot_raw || !scales3 || !opacities) { mgs::set_error("NULL tensor"); return 1; }
+    hipLaunchKernelGGL(mgs::activate_backward_kernel, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, P,
+                       scale_dim, rot_raw, scales3, opacities, grad_rotations, grad_scales3, grad_opacities, d_rot_raw,
+                       d_scale_raw, d_opacity_raw);
+    MGS_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // extern "C"

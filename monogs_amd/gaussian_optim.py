@@ -59,3 +59,44 @@ def add_densification_stats(viewspace_grad: torch.Tensor, radii: torch.Tensor, x
     with torch.cuda.device(radii.device):
         _lib.check(lib.mgs_densify_stats(P, g.data_ptr(), radii.contiguous().data_ptr(), p(xyz_gradient_accum), p(denom),
                                          p(max_radii_2d), _stream()), "mgs_densify_stats")
+
+
+class _Activate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rot_raw, scale_raw, opacity_raw):
+        lib = _lib.load()
+        rot_raw, scale_raw, opacity_raw = rot_raw.detach().contiguous(), scale_raw.detach().contiguous(), opacity_raw.detach().contiguous()
+        P, sd = rot_raw.shape[0], scale_raw.shape[1]
+        dev = rot_raw.device
+        rot = torch.empty(P, 4, device=dev)
+        scales3 = torch.empty(P, 3, device=dev)
+        opac = torch.empty(P, 1, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.mgs_activate_forward(P, sd, rot_raw.data_ptr(), scale_raw.data_ptr(), opacity_raw.data_ptr(),
+                                                rot.data_ptr(), scales3.data_ptr(), opac.data_ptr(), _stream()),
+                       "mgs_activate_forward")
+        ctx.save_for_backward(rot_raw, scales3, opac)
+        ctx.sd = sd
+        return rot, scales3, opac
+
+    @staticmethod
+    def backward(ctx, g_rot, g_scales3, g_opac):
+        lib = _lib.load()
+        rot_raw, scales3, opac = ctx.saved_tensors
+        P, dev = rot_raw.shape[0], rot_raw.device
+        need = ctx.needs_input_grad
+        d_rot = torch.empty(P, 4, device=dev) if need[0] else None
+        d_scale = torch.empty(P, ctx.sd, device=dev) if need[1] else None
+        d_opac = torch.empty(P, 1, device=dev) if need[2] else None
+        p = lambda t: None if t is None else t.contiguous().data_ptr()  # noqa: E731
+        keep = [t.contiguous() if t is not None else None for t in (g_rot, g_scales3, g_opac)]
+        with torch.cuda.device(dev):
+            _lib.check(lib.mgs_activate_backward(P, ctx.sd, rot_raw.data_ptr(), scales3.data_ptr(), opac.data_ptr(),
+                                                 p(keep[0]), p(keep[1]), p(keep[2]), p(d_rot), p(d_scale), p(d_opac),
+                                                 _stream()), "mgs_activate_backward")
+        return d_rot, d_scale, d_opac
+
+
+def activate(rot_raw: torch.Tensor, scale_raw: torch.Tensor, opacity_raw: torch.Tensor):
+    """(normalize(rot_raw), exp(scale_raw) expanded to [P,3], sigmoid(opacity_raw)) in one launch, differentiable."""
+    return _Activate.apply(rot_raw, scale_raw, opacity_raw)

@@ -28,7 +28,7 @@ from . import camera as cam
 from .knn import distCUDA2
 from .renderer import render
 from . import fused_losses, slam_losses
-from .gaussian_optim import GaussianAdam
+from .gaussian_optim import GaussianAdam, activate
 from .pose_optim import PoseAdam
 from .synthetic import make_scene
 
@@ -163,6 +163,9 @@ class GaussianMap:
 
 
 def _render(vp, intr, gmap: GaussianMap, bg):
+    if gmap.fused_adam and gmap._rotation.requires_grad:      # one launch for normalize / exp / sigmoid (+ backward)
+        rot, scales3, opac = activate(gmap._rotation, gmap._scaling, gmap._opacity)
+        return render(vp, intr, gmap.get_xyz, rot, scales3, opac, gmap.get_features, bg)
     return render(vp, intr, gmap.get_xyz, gmap.get_rotation, gmap.get_scaling, gmap.get_opacity, gmap.get_features, bg)
 
 

@@ -43,3 +43,23 @@ def test_densification_stats(native_lib):
     mr_r[vis] = torch.max(mr_r[vis], radii[vis].float())
     add_densification_stats(vs, radii, acc, den, mr)
     assert torch.allclose(acc, acc_r, rtol=1e-6, atol=1e-7) and torch.equal(den, den_r) and torch.equal(mr, mr_r)
+
+
+@pytest.mark.parametrize("sd", [1, 3])
+def test_fused_activations(native_lib, sd):
+    from monogs_amd.gaussian_optim import activate
+    g = torch.Generator().manual_seed(2)
+    P = 4001
+    raw = [torch.randn(P, 4, generator=g), torch.randn(P, sd, generator=g) - 3, torch.randn(P, 1, generator=g) * 2]
+    a = [t.to(DEV).requires_grad_(True) for t in raw]
+    b = [t.to(DEV).requires_grad_(True) for t in raw]
+    w = [torch.randn(P, 4, generator=g).to(DEV), torch.randn(P, 3, generator=g).to(DEV), torch.randn(P, 1, generator=g).to(DEV)]
+    outs = activate(*a)
+    sc = torch.exp(b[1])
+    refs = (torch.nn.functional.normalize(b[0]), sc.repeat(1, 3) if sd == 1 else sc, torch.sigmoid(b[2]))
+    for o, r in zip(outs, refs):
+        assert torch.allclose(o, r, rtol=1e-6, atol=1e-7)
+    sum((o * ww).sum() for o, ww in zip(outs, w)).backward()
+    sum((r * ww).sum() for r, ww in zip(refs, w)).backward()
+    for x, y in zip(a, b):
+        assert torch.allclose(x.grad, y.grad, rtol=1e-5, atol=1e-6), (x.grad - y.grad).abs().max()

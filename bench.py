@@ -183,6 +183,7 @@ def main():
         R = fw[0]["num_rendered"]
         Pv = int((state["radii"] > 0).sum().item())
         HW = H * W
+        P = args.gaussians
         # algorithmic bytes (SURVEY.md section 8d / BASELINE.md section 4)
         b_fwd = 44 * R + 28 * HW + 4 * Pv
         b_bwd = 44 * R + 24 * HW + 40 * Pv
@@ -195,12 +196,32 @@ def main():
                 traffic = json.load(open(tpath)).get("blend_backward_bytes_per_launch")
             except Exception:
                 traffic = None
+        # measured device-copy ceiling from the same run: 512 MiB device-to-device copy, read + write counted
+        src = torch.empty(512 << 20, dtype=torch.uint8, device=dev)
+        dst = torch.empty_like(src)
+        dst.copy_(src)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            dst.copy_(src)
+        e1.record()
+        torch.cuda.synchronize()
+        copy_gbs = 10 * 2 * src.numel() / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del src, dst
+        # all stages: SURVEY.md 8d per-stage algorithmic bytes (one ideal sort pass each for the two sorts)
+        b_all = (44 * P + 8 * P + 52 * Pv) + 8 * P + (16 * Pv + 12 * R) + 24 * R + (8 * R + 8 * ((W + 15) // 16) * ((H + 15) // 16)) \
+            + b_fwd + b_bwd + (44 * P + 40 * Pv + 68 * Pv + 24)
+        t_all = sum(stages.values())
         roof = {"bound": "hbm", "kernel": "blend_backward_kernel", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "algorithmic_bytes": b_bwd, "avg_ms": stages["blend_bwd_ms"],
                 "blend_fwd_bwd": {"achieved": round(both, 2), "frac": round(both / HBM_PEAK_GBS, 5),
                                   "algorithmic_bytes": b_fwd + b_bwd,
                                   "avg_ms": round(stages["blend_fwd_ms"] + stages["blend_bwd_ms"], 4)},
+                "all_stages": {"achieved": round(b_all / (t_all * 1e-3) / 1e9, 2), "algorithmic_bytes": b_all,
+                               "frac": round(b_all / (t_all * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "avg_ms": round(t_all, 4)},
+                "copy_ceiling": {"measured_gbs": round(copy_gbs, 1), "frac_of_copy": round(ach / copy_gbs, 5),
+                                 "blend_fwd_bwd_frac_of_copy": round(both / copy_gbs, 5)},
                 "num_rendered": R, "visible": Pv}
 
     log("stages_ms", stages)

@@ -198,3 +198,40 @@ def test_c5_full_size_properties(native_lib):
     g3, t3 = grads(3.0)
     assert ((g3 - 3 * g1).norm() / (3 * g1).norm()).item() < 1e-5
     assert ((t3 - 3 * t1).norm() / (3 * t1).norm()).item() < 1e-4
+
+
+def test_knn_morton_path(native_lib, monkeypatch):
+    """The Morton-box path (large clouds) against the all-pairs sweep (bit-identical) and the cKDTree oracle."""
+    import time
+    from monogs_amd.knn import distCUDA2
+    from oracle import dist2_knn
+    g = torch.Generator().manual_seed(5)
+    uniform = torch.rand(60000, 3, generator=g) * 6 - 3
+    # depth-map-like sheet + tight clusters + exact duplicates + a far outlier
+    sheet = torch.cat([torch.rand(30000, 2, generator=g) * 4, torch.rand(30000, 1, generator=g) * 0.01 + 2.0], 1)
+    clusters = torch.randn(20000, 3, generator=g) * 1e-3 + torch.randint(0, 5, (20000, 1), generator=g).float()
+    dup = uniform[:5000].clone()
+    mixed = torch.cat([sheet, clusters, dup, uniform[:5000], torch.tensor([[1e4, -1e4, 3e3]])])
+    for name, pts in (("uniform", uniform), ("mixed", mixed), ("tiny", uniform[:70]), ("same", torch.ones(300, 3))):
+        d = pts.to(DEV)
+        monkeypatch.setenv("MGS_KNN_GRID_MIN", "4")               # force the Morton-box path
+        grid = distCUDA2(d).cpu()
+        monkeypatch.setenv("MGS_KNN_GRID_MIN", str(1 << 30))      # force the all-pairs sweep
+        sweep = distCUDA2(d).cpu()
+        assert torch.equal(grid, sweep), (name, (grid - sweep).abs().max())
+        assert torch.allclose(grid, dist2_knn(pts), rtol=1e-5, atol=1e-9), name
+    monkeypatch.delenv("MGS_KNN_GRID_MIN")
+    # full size: 2 M points (the C5 map) in milliseconds; property check = every result is a true 3-NN mean on a sample
+    big = (torch.rand(2_000_000, 3, generator=g) * 20 - 10).to(DEV)
+    distCUDA2(big)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res = distCUDA2(big)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(f"distCUDA2 2M points: {dt * 1e3:.2f} ms")
+    sample = torch.randint(0, big.shape[0], (256,), generator=g).to(DEV)
+    d2 = ((big[sample][:, None, :] - big[None, :, :]) ** 2).sum(-1)
+    d2[torch.arange(256, device=DEV), sample] = float("inf")
+    ref = d2.topk(3, dim=1, largest=False).values.mean(1)
+    assert torch.allclose(res[sample], ref, rtol=1e-4, atol=1e-9)

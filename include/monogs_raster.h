@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define MGS_ABI_VERSION 2
+#define MGS_ABI_VERSION 3
 #define MGS_TILE 16 /* tile edge in pixels; ranges are per 16x16 tile */
 
 /* GaussianRasterizationSettings, minus `prefiltered` / `debug` which are call flags
@@ -177,12 +177,15 @@ int mgs_loss_backward(int32_t width, int32_t height, int32_t tracking, int32_t i
  * (order rot(3), trans(3), a, b) are device tensors updated in place; `step` is the 1-based Adam step, or, when
  * step_counter (device int32) is non-NULL, the counter is incremented on the device and used instead (so the call
  * can be captured in a hipGraph and replayed);
- * out[2] = {converged (|tau| < converged_threshold ? 1 : 0), |tau|}.  exposure pointers / any gradient may be NULL. */
+ * out[2] = {converged (|tau| < converged_threshold ? 1 : 0), |tau|}.  exposure pointers / any gradient may be NULL.
+ * flags: MGS_POSE_STICKY makes the call a no-op once out[0] reports convergence (the tracker's early exit,
+ * /root/reference/utils/slam_tracker.py:172-176, for loops replayed from a hipGraph); zero out[] to start over. */
+#define MGS_POSE_STICKY 1
 int mgs_pose_step(float* R, float* T, float* rot_delta, float* trans_delta, float* exposure_a, float* exposure_b,
                   const float* grad_rot, const float* grad_trans, const float* grad_a, const float* grad_b,
                   float* adam_m, float* adam_v, int32_t step, float lr_rot, float lr_trans, float lr_exposure,
                   float beta1, float beta2, float eps, float converged_threshold, int32_t* step_counter, float* out,
-                  void* stream);
+                  int32_t flags, void* stream);
 
 /* ---- Fused Gaussian optimiser step + densification statistics ---------------
  * mgs_adam_step: torch.optim.Adam defaults over n_tensors <= 8 float tensors in one launch (the reference's five

@@ -197,11 +197,10 @@ static int forward_render_impl(const mgs_camera* cam, int32_t P, uint64_t R, boo
     const uint32_t* n_dev = nullptr;
     StageTimer tm(s, timing != nullptr);
     if (capacity && binning) {
-        if (int rc = launch_clamp_count(g, P, R, b.count, s)) return rc;
+        if (int rc = launch_clamp_count(g, P, R, b.count, overflow, s)) return rc;
         n_dev = b.count;
-        if (overflow) MGS_HIP(hipMemcpyAsync(overflow, b.count + 1, sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
     } else if (overflow) {
-        MGS_HIP(hipMemsetAsync(overflow, 0, sizeof(uint32_t), s));
+        MGS_HIP(zero_fill(overflow, sizeof(uint32_t), s));
     }
     tm.mark();
     // (also zeroes n_touched and the tile ranges; with R == 0 it emits nothing)
@@ -248,7 +247,7 @@ int mgs_backward(const mgs_camera* cam, int32_t P, uint64_t R, const float* mean
     if (check_cam(cam)) return 1;
     hipStream_t s = (hipStream_t)stream;
     if (P == 0) {
-        if (dL_dtau) MGS_HIP(hipMemsetAsync(dL_dtau, 0, 6 * sizeof(float), s));
+        if (dL_dtau) MGS_HIP(zero_fill(dL_dtau, 6 * sizeof(float), s));
         return 0;
     }
     if (!means3D || !opacities || !radii || !geometry || !image || !dL_dcolor || !dL_ddepth || !backward_scratch) {
@@ -262,8 +261,8 @@ int mgs_backward(const mgs_camera* cam, int32_t P, uint64_t R, const float* mean
     BinningState b = BinningState::carve(const_cast<void*>(binning), R, W, H);
     float* grad_acc = (float*)align_up((size_t)backward_scratch, 256);
     StageTimer tm(s, timing != nullptr);
-    MGS_HIP(hipMemsetAsync(grad_acc, 0, (size_t)P * GRAD_FLOATS * sizeof(float), s));
-    if (dL_dtau) MGS_HIP(hipMemsetAsync(dL_dtau, 0, 6 * sizeof(float), s));
+    MGS_HIP(zero_fill(grad_acc, (size_t)P * GRAD_FLOATS * sizeof(float), s));
+    if (dL_dtau) MGS_HIP(zero_fill(dL_dtau, 6 * sizeof(float), s));
     tm.mark();
     if (R > 0) {
         if (int rc = launch_blend_backward(*cam, g, b, img, dL_dcolor, dL_ddepth, grad_acc, s)) return rc;

@@ -168,19 +168,17 @@ __global__ void __launch_bounds__(256) duplicate_kernel(int P, const float* __re
     }
 }
 
-__global__ void clamp_count_kernel(const uint32_t* __restrict__ offsets, int P, uint32_t r_cap, uint32_t* count) {
-    const uint32_t R = offsets[P - 1];
+__global__ void clamp_count_kernel(const uint32_t* __restrict__ offsets, int P, uint32_t r_cap, uint32_t* count,
+                                   uint32_t* overflow) {
+    const uint32_t R = P > 0 ? offsets[P - 1] : 0u;
     count[0] = min(R, r_cap);
     count[1] = R > r_cap ? 1u : 0u;
+    if (overflow) overflow[0] = count[1];          // the caller's flag, written here (no memcpy node in a captured graph)
 }
 
-int launch_clamp_count(const GeometryState& g, int P, uint64_t r_cap, uint32_t* count, hipStream_t s) {
-    if (P == 0) {
-        MGS_HIP(hipMemsetAsync(count, 0, 2 * sizeof(uint32_t), s));
-        return 0;
-    }
+int launch_clamp_count(const GeometryState& g, int P, uint64_t r_cap, uint32_t* count, uint32_t* overflow, hipStream_t s) {
     hipLaunchKernelGGL(clamp_count_kernel, dim3(1), dim3(1), 0, s, g.point_offsets, P,
-                       (uint32_t)(r_cap > 0xFFFFFFFFull ? 0xFFFFFFFFull : r_cap), count);
+                       (uint32_t)(r_cap > 0xFFFFFFFFull ? 0xFFFFFFFFull : r_cap), count, overflow);
     MGS_HIP(hipGetLastError());
     return 0;
 }

@@ -40,6 +40,33 @@ enum : int {
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// ---- zero fill as a plain kernel ------------------------------------------------------------
+// Every clear on the hot path is a kernel, never hipMemsetAsync / hipMemcpyAsync: inside a captured hipGraph
+// those become memset / memcpy NODES, and on this ROCm a graph holding them faulted ("write access to a
+// read-only page") once unrelated eager copies ran between two replays (tools/graph_probe.py).  Kernel nodes
+// replay exactly as launched.  `ptr` must be 4-byte aligned and `bytes` a multiple of 4.
+__global__ static void zero_fill_kernel(uint32_t* __restrict__ p, size_t n_words, int vec) {
+    const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+    if (vec) {
+        uint4* q = reinterpret_cast<uint4*>(p);
+        const size_t nv = n_words / 4;
+        for (size_t i = i0; i < nv; i += stride) q[i] = make_uint4(0u, 0u, 0u, 0u);
+        for (size_t i = nv * 4 + i0; i < n_words; i += stride) p[i] = 0u;
+    } else {
+        for (size_t i = i0; i < n_words; i += stride) p[i] = 0u;
+    }
+}
+static inline hipError_t zero_fill(void* ptr, size_t bytes, hipStream_t s) {
+    if (bytes == 0) return hipSuccess;
+    const size_t n_words = bytes / 4;
+    const int vec = ((size_t)ptr % 16 == 0) ? 1 : 0;
+    const size_t items = vec ? (n_words + 3) / 4 : n_words;
+    size_t blocks = (items + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (uint32_t*)ptr, n_words, vec);
+    return hipGetLastError();
+}
+
 // ---- scratch carving (every sub-buffer 256-byte aligned) ---------------------------------
 struct GeometryState {
     float* rec;               // [P][16]
@@ -113,7 +140,7 @@ int launch_preprocess_forward(const mgs_camera& cam, int P, const float* means3D
                               const GeometryState& g, int32_t* radii, hipStream_t s);
 int launch_scan(const GeometryState& g, int P, hipStream_t s);
 // `r_cap`: capacity of the binning buffers; `count` (device): [0] live instance count min(R, r_cap), [1] overflow flag
-int launch_clamp_count(const GeometryState& g, int P, uint64_t r_cap, uint32_t* count, hipStream_t s);
+int launch_clamp_count(const GeometryState& g, int P, uint64_t r_cap, uint32_t* count, uint32_t* overflow, hipStream_t s);
 int launch_duplicate(const mgs_camera& cam, int P, const GeometryState& g, const BinningState& b, uint64_t r_cap,
                      int32_t* n_touched, const ImageState& img, hipStream_t s);
 size_t sort_temp_bytes(uint64_t n, int bits);

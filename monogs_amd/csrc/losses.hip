@@ -183,7 +183,7 @@ int launch_loss_forward(const LossArgs& a, float* partials, float* loss_out, hip
 
 int launch_loss_backward(const LossArgs& a, const float* partials, const float* grad_out, float* d_render,
                          float* d_depth, float* d_ab, hipStream_t s) {
-    if (d_ab) MGS_HIP(hipMemsetAsync(d_ab, 0, 2 * sizeof(float), s));
+    if (d_ab) MGS_HIP(zero_fill(d_ab, 2 * sizeof(float), s));
     hipLaunchKernelGGL(loss_backward_kernel, dim3(loss_grid(a.W, a.H)), dim3(LS_THREADS), 0, s, a, partials, grad_out,
                        d_render, d_depth, d_ab);
     MGS_HIP(hipGetLastError());

@@ -24,6 +24,7 @@ struct PoseStepArgs {
     float lr_rot, lr_trans, lr_exp, beta1, beta2, eps, converged_threshold;
     int step;             // 1-based Adam step count of this update (used when step_dev is NULL)
     int* step_dev;        // optional device counter: incremented here, so a captured graph replays correctly
+    int flags;            // MGS_POSE_STICKY: once out[0] says converged, later calls change nothing
 };
 
 __device__ __forceinline__ void mat3mul(const float* A, const float* B, float* C) {
@@ -33,6 +34,10 @@ __device__ __forceinline__ void mat3mul(const float* A, const float* B, float* C
 
 __global__ void pose_step_kernel(PoseStepArgs a) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    // Sticky convergence: the reference's tracker leaves its loop at the first converged update
+    // (/root/reference/utils/slam_tracker.py:172-176).  With the loop replayed from a hipGraph the host learns of the
+    // convergence one replay late; making that extra replay a no-op keeps the result identical to the early exit.
+    if ((a.flags & 1) && a.out[0] > 0.5f) return;
     // ---- Adam (torch.optim.Adam defaults: no weight decay, no amsgrad), one scalar at a time
     int step = a.step;
     if (a.step_dev) { step = a.step_dev[0] + 1; a.step_dev[0] = step; }
@@ -95,7 +100,8 @@ extern "C" int mgs_pose_step(float* R, float* T, float* rot_delta, float* trans_
                              float* exposure_b, const float* grad_rot, const float* grad_trans, const float* grad_a,
                              const float* grad_b, float* adam_m, float* adam_v, int32_t step, float lr_rot,
                              float lr_trans, float lr_exposure, float beta1, float beta2, float eps,
-                             float converged_threshold, int32_t* step_counter, float* out, void* stream) {
+                             float converged_threshold, int32_t* step_counter, float* out, int32_t flags,
+                             void* stream) {
     if (!R || !T || !rot_delta || !trans_delta || !adam_m || !adam_v || !out) {
         set_error("R, T, rot_delta, trans_delta, adam_m, adam_v, out must be non-NULL");
         return 1;
@@ -105,7 +111,7 @@ extern "C" int mgs_pose_step(float* R, float* T, float* rot_delta, float* trans_
     a.R = R; a.T = T; a.rot_delta = rot_delta; a.trans_delta = trans_delta; a.exp_a = exposure_a; a.exp_b = exposure_b;
     a.g_rot = grad_rot; a.g_trans = grad_trans; a.g_a = grad_a; a.g_b = grad_b; a.m = adam_m; a.v = adam_v; a.out = out;
     a.lr_rot = lr_rot; a.lr_trans = lr_trans; a.lr_exp = lr_exposure; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
-    a.converged_threshold = converged_threshold; a.step = step; a.step_dev = step_counter;
+    a.converged_threshold = converged_threshold; a.step = step; a.step_dev = step_counter; a.flags = flags;
     hipLaunchKernelGGL(pose_step_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a);
     MGS_HIP(hipGetLastError());
     return 0;

@@ -299,7 +299,7 @@ int radix_sort_pairs(uint32_t* ka, uint32_t* va, uint32_t* kb, uint32_t* vb, uin
     const int npasses = rs_passes(bits);
     if (npasses > RS_MAX_PASSES) { set_error("radix sort: more than 32 key bits"); return 1; }
     const RsTemp t = rs_carve(temp, n, bits);
-    MGS_HIP(hipMemsetAsync(t.hist, 0, t.zero_bytes, s));
+    MGS_HIP(zero_fill(t.hist, t.zero_bytes, s));
     const uint32_t tiles = rs_tiles(n);
     const uint32_t hist_blocks = min(tiles, 1024u);
     hipLaunchKernelGGL(rs_hist_kernel, dim3(hist_blocks), dim3(RS_THREADS), 0, s, ka, (uint32_t)n, n_dev, npasses, t.hist);

@@ -14,8 +14,10 @@ from .rasterizer import _stream
 
 
 class PoseAdam:
-    def __init__(self, viewpoint, lr_rot=0.003, lr_trans=0.001, lr_exposure=0.01, betas=(0.9, 0.999), eps=1e-8):
+    def __init__(self, viewpoint, lr_rot=0.003, lr_trans=0.001, lr_exposure=0.01, betas=(0.9, 0.999), eps=1e-8,
+                 sticky=False):
         self.vp = viewpoint
+        self.sticky = bool(sticky)   # once converged, further steps are no-ops (graph-replayed tracking loops)
         self.lrs = (float(lr_rot), float(lr_trans), float(lr_exposure))
         self.betas, self.eps = betas, eps
         dev = viewpoint.cam_rot_delta.device
@@ -23,6 +25,12 @@ class PoseAdam:
         self.v = torch.zeros(8, device=dev)
         self.out = torch.zeros(2, device=dev)
         self.t_dev = torch.zeros(1, dtype=torch.int32, device=dev)     # Adam step count lives on the device
+
+    @torch.no_grad()
+    def reset(self):
+        """Fresh optimiser state (what constructing a new torch.optim.Adam per frame does in the reference,
+        /root/reference/utils/slam_tracker.py:113-140) without re-allocating: captured graphs keep pointing at it."""
+        self.m.zero_(); self.v.zero_(); self.out.zero_(); self.t_dev.zero_()
 
     def zero_grad(self):
         vp = self.vp
@@ -46,6 +54,6 @@ class PoseAdam:
                                          g(vp.exposure_a), g(vp.exposure_b), self.m.data_ptr(), self.v.data_ptr(),
                                          0, self.lrs[0], self.lrs[1], self.lrs[2], self.betas[0], self.betas[1],
                                          self.eps, float(converged_threshold), self.t_dev.data_ptr(),
-                                         self.out.data_ptr(), _stream()),
+                                         self.out.data_ptr(), 1 if self.sticky else 0, _stream()),
                        "mgs_pose_step")
         return bool(self.out[0].item() > 0.5) if sync else self.out

@@ -169,49 +169,90 @@ def _render(vp, intr, gmap: GaussianMap, bg):
     return render(vp, intr, gmap.get_xyz, gmap.get_rotation, gmap.get_scaling, gmap.get_opacity, gmap.get_features, bg)
 
 
-def _track_frame_graph(vp, intr, gmap, bg, max_iters):
-    """One frame of tracking with the iteration (render -> fused loss -> backward -> fused pose step) captured
-    in a hipGraph and replayed: the forward runs in capacity mode (no host sync), the Adam step count and the
-    convergence flag live on the device, so an iteration costs one graph launch plus one 4-byte read-back.
-    The map is constant during tracking, so its activations are evaluated once and it takes no gradient."""
-    from . import rasterizer as _r
-    with torch.no_grad():
-        xyz, rot, sca = gmap.get_xyz.detach(), gmap.get_rotation.detach(), gmap.get_scaling.detach()
-        opa, col = gmap.get_opacity.detach(), gmap.get_features.detach()
-    opt = PoseAdam(vp, 0.003, 0.001, 0.01)
+class TrackingGraph:
+    """The tracking iteration (render -> fused loss -> backward -> fused pose step) captured ONCE per map version
+    in a hipGraph and replayed for every iteration of every frame tracked against that map.
 
-    def iteration():
-        pkg = render(vp, intr, xyz, rot, sca, opa, col, bg)
-        opt.zero_grad()
-        loss = fused_losses.get_loss_tracking(pkg["render"], pkg["depth"], pkg["opacity"], vp)
+    * The forward runs in capacity mode (no host sync); the Adam step count and a sticky convergence flag live on the
+      device, so a replay that runs after convergence changes nothing.
+    * The frame being tracked is copied into a static viewpoint whose buffers the graph points at; the map is constant
+      during tracking, so its activations are evaluated once and it takes no gradient.
+    * The convergence flag is read back through a pinned buffer after every replay (or one replay late, `lookahead`).
+    Result: identical poses and iteration counts to the eager loop with its per-iteration `if converged: break`."""
+
+    def __init__(self, proto: Viewpoint, intr, gmap, bg):
+        from . import rasterizer as _r
+        self._r = _r
+        dev = proto.device
+        with torch.no_grad():
+            self.map = (gmap.get_xyz.detach(), gmap.get_rotation.detach(), gmap.get_scaling.detach(),
+                        gmap.get_opacity.detach(), gmap.get_features.detach())
+        self.n_gaussians = int(self.map[0].shape[0])
+        self.svp = Viewpoint(-1, torch.zeros_like(proto.rgb), torch.ones_like(proto.depth), dev)
+        self.opt = PoseAdam(self.svp, 0.003, 0.001, 0.01, sticky=True)
+        self.intr, self.bg = intr, bg
+        self.flags = [torch.zeros(1, pin_memory=True) for _ in range(2)]
+        self.events = [torch.cuda.Event() for _ in range(2)]
+        self.graph = None
+        self._load(proto)
+        keep = (self.svp.R.clone(), self.svp.T.clone(), self.svp.exposure_a.data.clone(), self.svp.exposure_b.data.clone())
+        # eager warm-up on a side stream (also records the capacity hint for this map size), then capture
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            self._iteration()
+        torch.cuda.current_stream().wait_stream(s)
+        self.opt.zero_grad()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self._iteration()
+        with torch.no_grad():          # undo the warm-up step
+            self.svp.R.copy_(keep[0]); self.svp.T.copy_(keep[1])
+            self.svp.exposure_a.data.copy_(keep[2]); self.svp.exposure_b.data.copy_(keep[3])
+
+    def _iteration(self):
+        pkg = render(self.svp, self.intr, *self.map, self.bg)
+        self.opt.zero_grad()
+        loss = fused_losses.get_loss_tracking(pkg["render"], pkg["depth"], pkg["opacity"], self.svp)
         loss.backward()
-        opt.step_and_retract(sync=False)
+        self.opt.step_and_retract(sync=False)
 
-    # eager warm-up on a side stream (also records the capacity hint for this map size), then capture
-    s = torch.cuda.Stream()
-    s.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(s):
-        iteration()
-    torch.cuda.current_stream().wait_stream(s)
-    n_it = 1
-    if bool(opt.out[0].item() > 0.5):
-        return n_it
-    graph = torch.cuda.CUDAGraph()
-    opt.zero_grad()
-    with torch.cuda.graph(graph):
-        iteration()
-    n_it += 1                                     # the capture pass does not execute; replay it once now
-    graph.replay()
-    while n_it < max_iters:
-        if bool(opt.out[0].item() > 0.5):
-            break
-        graph.replay()
-        n_it += 1
-    if _r.check_overflow():
-        raise RuntimeError("binning capacity overflow inside the captured tracking graph")
-    _r.clear_graph_flags()
-    del graph
-    return n_it
+    @torch.no_grad()
+    def _load(self, vp: Viewpoint):
+        s = self.svp
+        s.rgb.copy_(vp.rgb); s.depth.copy_(vp.depth); s.mask.copy_(vp.mask); s.grad_mask.copy_(vp.grad_mask)
+        s.R.copy_(vp.R); s.T.copy_(vp.T)
+        s.exposure_a.data.copy_(vp.exposure_a.data); s.exposure_b.data.copy_(vp.exposure_b.data)
+        s.cam_rot_delta.data.zero_(); s.cam_trans_delta.data.zero_()
+        self.opt.reset()
+
+    def track(self, vp: Viewpoint, max_iters: int, lookahead: int = 0) -> int:
+        """lookahead = 0: read the convergence flag after every replay (one 4-byte read-back per iteration).
+        lookahead = 1: launch replay n before reading the flag of replay n-1 (hides the read-back; relies on the sticky
+        flag making the surplus replay a no-op)."""
+        self._load(vp)
+        n_done = max_iters
+        for n in range(max_iters):
+            self.graph.replay()
+            self.flags[n & 1].copy_(self.opt.out[:1], non_blocking=True)
+            self.events[n & 1].record()
+            m = n - lookahead
+            if m >= 0:
+                self.events[m & 1].synchronize()
+                if float(self.flags[m & 1][0]) > 0.5:       # iteration m converged; any later replay was a no-op
+                    n_done = m + 1
+                    break
+        torch.cuda.current_stream().synchronize()
+        if self._r.check_overflow():
+            raise RuntimeError("binning capacity overflow inside the captured tracking graph")
+        with torch.no_grad():
+            vp.R, vp.T = self.svp.R.clone(), self.svp.T.clone()
+            vp.exposure_a.data.copy_(self.svp.exposure_a.data); vp.exposure_b.data.copy_(self.svp.exposure_b.data)
+        return n_done
+
+    def close(self):
+        self._r.clear_graph_flags()
+        self.graph = None
 
 
 def make_sequence(n_frames: int, intrinsics="fr3_office", n_gaussians=60000, seed=11, device="cuda:0"):
@@ -320,6 +361,7 @@ def run_slam(n_frames=12, intrinsics="fr3_office", tracking_itr_num=100, mapping
 
     for i, vp in enumerate(frames):
         if i == 0:
+            tgraph = None
             vp.update_RT(vp.R_gt, vp.T_gt)
             sync(); t0 = time.perf_counter()
             gmap.extend_from_frame(vp, intr, downsample=init_downsample, init=True, point_size=point_size)
@@ -333,7 +375,9 @@ def run_slam(n_frames=12, intrinsics="fr3_office", tracking_itr_num=100, mapping
         vp.update_RT(prev.R.clone(), prev.T.clone())     # the fused pose step updates R, T in place
         if graph_tracking:
             sync(); t0 = time.perf_counter()
-            n_it = _track_frame_graph(vp, intr, gmap, bg, tracking_itr_num)
+            if tgraph is None:                       # the map changed (or first frame): capture against the new map
+                tgraph = TrackingGraph(vp, intr, gmap, bg)
+            n_it = tgraph.track(vp, tracking_itr_num)
             sync(); stats["track_s"] += time.perf_counter() - t0
             stats["track_iters"] += n_it
             stats["renders"] += n_it
@@ -381,6 +425,9 @@ def run_slam(n_frames=12, intrinsics="fr3_office", tracking_itr_num=100, mapping
             map_window(mapping_itr_num)
             sync(); stats["map_s"] += time.perf_counter() - t0
             stats["keyframes"] += 1
+            if tgraph is not None:                   # the map changed: the captured tracking graph is stale
+                tgraph.close()
+                tgraph = None
         if log:
             e = (-(vp.R.t() @ vp.T) + (vp.R_gt.t() @ vp.T_gt)).norm().item()
             with torch.no_grad():
@@ -388,6 +435,8 @@ def run_slam(n_frames=12, intrinsics="fr3_office", tracking_itr_num=100, mapping
             log(f"frame {i}: P={gmap.get_xyz.shape[0]} track_iters={stats['track_iters']} kf={stats['keyframes']} "
                 f"pos_err={e:.4f} m  opaque>0.99={cov:.2f} last_loss={float(loss):.5f}")
 
+    if graph_tracking and tgraph is not None:
+        tgraph.close()
     err = torch.stack([(-(f.R.t() @ f.T) + (f.R_gt.t() @ f.T_gt)).norm() for f in frames[1:]])
     out = dict(stats)
     out.update(frames=n_frames, gaussians=int(gmap.get_xyz.shape[0]), width=intr.width, height=intr.height,

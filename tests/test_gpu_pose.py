@@ -43,3 +43,26 @@ def test_pose_step_matches_adam_plus_update_pose(native_lib):
         assert a.cam_rot_delta.abs().max() == 0 and a.cam_trans_delta.abs().max() == 0
     # rotation stays orthonormal
     assert torch.allclose(a.R @ a.R.t(), torch.eye(3, device=DEV), atol=1e-5)
+
+
+def test_pose_step_sticky_convergence(native_lib):
+    """MGS_POSE_STICKY: after the first converged update every further call is a no-op until reset()."""
+    from monogs_amd.pose_optim import PoseAdam
+    a = _vp(1)
+    opt = PoseAdam(a, sticky=True)
+    big, tiny = torch.full((3,), 0.5, device=DEV), torch.full((3,), 1e-12, device=DEV)
+
+    def step(g, thr):
+        a.cam_rot_delta.grad, a.cam_trans_delta.grad = g.clone(), g.clone()
+        a.exposure_a.grad, a.exposure_b.grad = g[:1].clone(), g[:1].clone()
+        return opt.step_and_retract(converged_threshold=thr)
+
+    assert step(big, 1e-4) is False
+    assert step(big, 1.0) is True                      # |tau| < 1: converged
+    snap = [t.clone() for t in (a.R, a.T, a.exposure_a.data, a.exposure_b.data, opt.m, opt.v, opt.t_dev)]
+    assert step(big, 1e-4) is True                     # sticky: nothing moves, flag stays
+    for t, s in zip((a.R, a.T, a.exposure_a.data, a.exposure_b.data, opt.m, opt.v, opt.t_dev), snap):
+        assert torch.equal(t, s)
+    opt.reset()
+    assert int(opt.t_dev) == 0 and step(big, 1e-4) is False and int(opt.t_dev) == 1
+    assert not torch.equal(a.R, snap[0])

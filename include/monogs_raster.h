@@ -187,6 +187,15 @@ int mgs_pose_step(float* R, float* T, float* rot_delta, float* trans_delta, floa
                   float beta1, float beta2, float eps, float converged_threshold, int32_t* step_counter, float* out,
                   int32_t flags, void* stream);
 
+/* ---- Camera matrices of one viewpoint ---------------------------------
+ * From the world->camera rotation R[3,3] (row-major) and translation T[3] and the transposed projection
+ * projmatrix_raw[4,4]: viewmatrix = getWorld2View(R, T)^T (/root/reference/gaussian_splatting/utils/graphics_utils.py:33-42,
+ * /root/reference/utils/camera_utils.py:171-174), projmatrix = viewmatrix @ projmatrix_raw
+ * (/root/reference/utils/camera_utils.py:224-231), campos = viewmatrix^-1[3,:3] = -R^T T
+ * (/root/reference/utils/camera_utils.py:176-178).  One launch; all pointers are device memory. */
+int mgs_camera_setup(const float* R, const float* T, const float* projmatrix_raw, float* viewmatrix /* [16] */,
+                     float* projmatrix /* [16] */, float* campos /* [3] */, void* stream);
+
 /* ---- Fused Gaussian optimiser step + densification statistics ---------------
  * mgs_adam_step: torch.optim.Adam defaults over n_tensors <= 8 float tensors in one launch (the reference's five
  * groups: /root/reference/gaussian_splatting/scene/gaussian_model.py:398-442).  All tables are HOST arrays of

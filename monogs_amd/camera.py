@@ -34,6 +34,25 @@ def world2view(R: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
     return M
 
 
+def fused_camera_matrices(R: torch.Tensor, t: torch.Tensor, projmatrix_raw: torch.Tensor):
+    """(viewmatrix, projmatrix, campos) -- the three transposed camera tensors of GaussianRasterizationSettings --
+    from device tensors R[3,3], t[3] (world->camera) and the transposed projection, in one launch
+    (``mgs_camera_setup``).  Same values as ``world2view(R, t).T``, ``viewmatrix @ projmatrix_raw`` and
+    ``viewmatrix.inverse()[3, :3]``; no autograd (the rasteriser gives the camera tensors no gradient)."""
+    from . import _lib
+    lib = _lib.load()
+    f = lambda x: x.detach().to(torch.float32).contiguous()  # noqa: E731
+    R, t, Pm = f(R), f(t), f(projmatrix_raw)
+    dev = R.device
+    view = torch.empty(4, 4, dtype=torch.float32, device=dev)
+    full = torch.empty(4, 4, dtype=torch.float32, device=dev)
+    campos = torch.empty(3, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.mgs_camera_setup(R.data_ptr(), t.data_ptr(), Pm.data_ptr(), view.data_ptr(), full.data_ptr(),
+                                        campos.data_ptr(), torch.cuda.current_stream().cuda_stream), "mgs_camera_setup")
+    return view, full, campos
+
+
 def projection_matrix(fx, fy, cx, cy, W, H, znear=ZNEAR, zfar=ZFAR, device="cpu") -> torch.Tensor:
     """Off-centre pinhole projection, z in [znear, zfar] -> [0, 1], w = z (un-transposed)."""
     fx_t = torch.as_tensor([float(fx)], dtype=torch.float32, device=device)

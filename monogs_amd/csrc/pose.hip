@@ -92,9 +92,43 @@ __global__ void pose_step_kernel(PoseStepArgs a) {
     for (int i = 0; i < 3; ++i) { a.rot_delta[i] = 0.f; a.trans_delta[i] = 0.f; }
 }
 
+// Camera matrices of one viewpoint in ONE launch: what the reference assembles per render() from R, T with
+// getWorld2View + transpose, a 4x4 bmm and a 4x4 inverse
+// (/root/reference/gaussian_splatting/utils/graphics_utils.py:33-42, /root/reference/utils/camera_utils.py:171-178,
+// /root/reference/gaussian_splatting/gaussian_renderer/__init__.py:61-68) -- about ten small kernels in PyTorch.
+// All matrices are the TRANSPOSED (row-vector) ones the rasteriser takes.
+__global__ void camera_setup_kernel(const float* __restrict__ R, const float* __restrict__ T,
+                                    const float* __restrict__ proj_T, float* __restrict__ view_T,
+                                    float* __restrict__ full_T, float* __restrict__ campos) {
+    const int t = threadIdx.x;
+    auto vT = [&](int i, int k) -> float {          // view_T[i][k] = W2C[k][i],  W2C = [[R, t], [0, 1]]
+        if (k < 3) return i < 3 ? R[3 * k + i] : T[k];
+        return i == 3 ? 1.f : 0.f;
+    };
+    if (t < 16) {
+        const int i = t >> 2, j = t & 3;
+        view_T[t] = vT(i, j);
+        float acc = 0.f;
+        for (int k = 0; k < 4; ++k) acc += vT(i, k) * proj_T[4 * k + j];
+        full_T[t] = acc;
+    } else if (t < 19) {
+        const int i = t - 16;                       // camera centre -R^T t
+        campos[i] = -(R[i] * T[0] + R[3 + i] * T[1] + R[6 + i] * T[2]);
+    }
+}
+
 }  // namespace mgs
 
 using namespace mgs;
+
+extern "C" int mgs_camera_setup(const float* R, const float* T, const float* projmatrix_raw, float* viewmatrix,
+                                float* projmatrix, float* campos, void* stream) {
+    if (!R || !T || !projmatrix_raw || !viewmatrix || !projmatrix || !campos) { set_error("mgs_camera_setup: NULL argument"); return 1; }
+    hipLaunchKernelGGL(camera_setup_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, R, T, projmatrix_raw, viewmatrix,
+                       projmatrix, campos);
+    MGS_HIP(hipGetLastError());
+    return 0;
+}
 
 extern "C" int mgs_pose_step(float* R, float* T, float* rot_delta, float* trans_delta, float* exposure_a,
                              float* exposure_b, const float* grad_rot, const float* grad_trans, const float* grad_a,

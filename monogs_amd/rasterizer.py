@@ -161,7 +161,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                     C.byref(cam), P, _ptr(means3D), _ptr(sh_), _ptr(col_), _ptr(opac_), _ptr(sc_), _ptr(rot_),
                     _ptr(cov_), geom.data_ptr(), radii.data_ptr(), None, tref, _stream()), "mgs_forward_preprocess")
                 binning = torch.empty(lib.mgs_binning_bytes(R, W, H), **u8)
-                overflow = torch.zeros(1, dtype=torch.int32, device=dev)
+                overflow = torch.empty(1, dtype=torch.int32, device=dev)      # written by the clamp kernel
                 _lib.check(lib.mgs_forward_render_capacity(
                     C.byref(cam), P, R, geom.data_ptr(), binning.data_ptr(), img.data_ptr(), color.data_ptr(),
                     depth.data_ptr(), opacity.data_ptr(), n_touched.data_ptr(), overflow.data_ptr(), tref, _stream()),

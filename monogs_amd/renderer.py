@@ -14,6 +14,7 @@ import math
 
 import torch
 
+from .camera import fused_camera_matrices
 from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
 
 
@@ -30,23 +31,27 @@ def render(viewpoint_camera, cam_intrinsics, means, rotations, scales, opacity, 
     if means.shape[0] == 0:
         return None
     # zero tensor whose .grad receives the screen-space mean gradients
-    screenspace_points = torch.zeros_like(means, dtype=means.dtype, requires_grad=True, device=means.device) + 0
-    try:
-        screenspace_points.retain_grad()
-    except Exception:
-        pass
+    # (a leaf: the reference adds `+ 0` and calls retain_grad(); `.grad` is populated either way, with one kernel less)
+    screenspace_points = torch.zeros_like(means, dtype=means.dtype, requires_grad=True, device=means.device)
 
     tanfovx = math.tan(cam_intrinsics.FoVx * 0.5)
     tanfovy = math.tan(cam_intrinsics.FoVy * 0.5)
     projection_matrix = cam_intrinsics.projection_matrix
-    world_view = viewpoint_camera.world_view_transform
-    full_proj = (world_view.unsqueeze(0).bmm(projection_matrix.unsqueeze(0))).squeeze(0)
+    R, T = getattr(viewpoint_camera, "R", None), getattr(viewpoint_camera, "T", None)
+    if (torch.is_tensor(R) and torch.is_tensor(T) and R.is_cuda and T.is_cuda and R.shape == (3, 3) and T.shape == (3,)
+            and projection_matrix.is_cuda):
+        # the reference's camera objects carry R, T (utils/camera_utils.py:82-221): all three camera tensors in one launch
+        world_view, full_proj, campos = fused_camera_matrices(R, T, projection_matrix)
+    else:
+        world_view = viewpoint_camera.world_view_transform
+        full_proj = (world_view.unsqueeze(0).bmm(projection_matrix.unsqueeze(0))).squeeze(0)
+        campos = _camera_center(world_view)
 
     raster_settings = GaussianRasterizationSettings(
         image_height=int(cam_intrinsics.height), image_width=int(cam_intrinsics.width),
         tanfovx=tanfovx, tanfovy=tanfovy, bg=bg_color, scale_modifier=scaling_modifier,
         viewmatrix=world_view, projmatrix=full_proj, projmatrix_raw=projection_matrix,
-        sh_degree=0, campos=_camera_center(world_view), prefiltered=False, debug=False)
+        sh_degree=0, campos=campos, prefiltered=False, debug=False)
 
     if scales.shape[-1] == 1:          # isotropic map
         scales = scales.repeat(1, 3)

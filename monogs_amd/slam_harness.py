@@ -185,7 +185,9 @@ class TrackingGraph:
         self._r = _r
         dev = proto.device
         with torch.no_grad():
-            self.map = (gmap.get_xyz.detach(), gmap.get_rotation.detach(), gmap.get_scaling.detach(),
+            sca = gmap.get_scaling.detach()
+            self.map = (gmap.get_xyz.detach(), gmap.get_rotation.detach(),
+                        sca.repeat(1, 3) if sca.shape[-1] == 1 else sca,      # the isotropic expansion, once per map
                         gmap.get_opacity.detach(), gmap.get_features.detach())
         self.n_gaussians = int(self.map[0].shape[0])
         self.svp = Viewpoint(-1, torch.zeros_like(proto.rgb), torch.ones_like(proto.depth), dev)
@@ -283,7 +285,8 @@ def make_sequence(n_frames: int, intrinsics="fr3_office", n_gaussians=60000, see
 
 def run_slam(n_frames=12, intrinsics="fr3_office", tracking_itr_num=100, mapping_itr_num=150, window_size=8,
              kf_interval=4, init_itr_num=300, n_gaussians=60000, device="cuda:0", log=None,
-             init_downsample=8, kf_downsample=16, point_size=1.0, fused_losses_on=True, fused_pose_on=True, graph_tracking=False, graph_mapping=False):
+             init_downsample=8, kf_downsample=16, point_size=1.0, fused_losses_on=True, fused_pose_on=True, graph_tracking=False, graph_mapping=False,
+             track_lookahead=0):
     """Returns a dict with tracking / mapping FPS, iterations and the trajectory error."""
     frames, intr = make_sequence(n_frames, intrinsics, n_gaussians, device=device)
     L = fused_losses if fused_losses_on else slam_losses
@@ -377,7 +380,7 @@ def run_slam(n_frames=12, intrinsics="fr3_office", tracking_itr_num=100, mapping
             sync(); t0 = time.perf_counter()
             if tgraph is None:                       # the map changed (or first frame): capture against the new map
                 tgraph = TrackingGraph(vp, intr, gmap, bg)
-            n_it = tgraph.track(vp, tracking_itr_num)
+            n_it = tgraph.track(vp, tracking_itr_num, lookahead=track_lookahead)
             sync(); stats["track_s"] += time.perf_counter() - t0
             stats["track_iters"] += n_it
             stats["renders"] += n_it

@@ -29,13 +29,15 @@ if __name__ == "__main__":
     ap.add_argument("--eager-mapping", action="store_true", help="with --graph: capture tracking only")
     ap.add_argument("--torch-pose", action="store_true", help="torch.optim.Adam + Python retraction instead of mgs_pose_step")
     ap.add_argument("--torch-losses", action="store_true", help="use the plain PyTorch losses instead of the fused HIP ones")
+    ap.add_argument("--lookahead", type=int, default=0, choices=[0, 1],
+                    help="with --graph: read the convergence flag of tracking iteration n-1 while n runs")
     a = ap.parse_args()
     from monogs_amd.slam_harness import run_slam
     cfg = dict(CONFIGS[a.config])
     if a.mapping_iters is not None:
         cfg["mapping_itr_num"] = a.mapping_iters
     out = run_slam(n_frames=a.frames, init_itr_num=a.init_iters, n_gaussians=a.gaussians,
-                   fused_losses_on=not a.torch_losses, fused_pose_on=not a.torch_pose, graph_tracking=a.graph, graph_mapping=a.graph and not a.eager_mapping,
+                   fused_losses_on=not a.torch_losses, fused_pose_on=not a.torch_pose, graph_tracking=a.graph, graph_mapping=a.graph and not a.eager_mapping, track_lookahead=a.lookahead,
                    log=lambda s: print("[slam]", s, file=sys.stderr, flush=True), **cfg)
     out["workload"] = f"synthetic {a.config}-like sequence, {a.frames} frames"
     print(json.dumps(out))

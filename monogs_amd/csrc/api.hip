@@ -196,15 +196,14 @@ static int forward_render_impl(const mgs_camera* cam, int32_t P, uint64_t R, boo
     BinningState b = BinningState::carve(binning, R, W, H);
     const uint32_t* n_dev = nullptr;
     StageTimer tm(s, timing != nullptr);
-    if (capacity && binning) {
-        if (int rc = launch_clamp_count(g, P, R, b.count, overflow, s)) return rc;
-        n_dev = b.count;
-    } else if (overflow) {
-        MGS_HIP(zero_fill(overflow, sizeof(uint32_t), s));
-    }
+    const bool cap = capacity && binning;
+    if (cap) n_dev = b.count;
+    else if (overflow) MGS_HIP(zero_fill(overflow, sizeof(uint32_t), s));
     tm.mark();
-    // (also zeroes n_touched and the tile ranges; with R == 0 it emits nothing)
-    if (int rc = launch_duplicate(*cam, P, g, b, capacity ? R : (R > 0 ? 0xFFFFFFFFull : 0ull), n_touched, img, s)) return rc;
+    // (also zeroes n_touched, the tile ranges and the scratch of the tile sort; in capacity mode it publishes the
+    //  clamped live count and the overflow flag; with R == 0 it emits nothing)
+    if (int rc = launch_duplicate(*cam, P, g, b, capacity ? R : (R > 0 ? 0xFFFFFFFFull : 0ull), n_touched, img, R,
+                                  tile_bits(W, H), cap ? b.count : nullptr, cap ? overflow : nullptr, s)) return rc;
     tm.mark();
     if (int rc = launch_sort(b, R, tile_bits(W, H), s, n_dev)) return rc;
     tm.mark();
@@ -261,8 +260,7 @@ int mgs_backward(const mgs_camera* cam, int32_t P, uint64_t R, const float* mean
     BinningState b = BinningState::carve(const_cast<void*>(binning), R, W, H);
     float* grad_acc = (float*)align_up((size_t)backward_scratch, 256);
     StageTimer tm(s, timing != nullptr);
-    MGS_HIP(zero_fill(grad_acc, (size_t)P * GRAD_FLOATS * sizeof(float), s));
-    if (dL_dtau) MGS_HIP(zero_fill(dL_dtau, 6 * sizeof(float), s));
+    MGS_HIP(zero_fill2(grad_acc, (size_t)P * GRAD_FLOATS * sizeof(float), dL_dtau, 6 * sizeof(float), s));
     tm.mark();
     if (R > 0) {
         if (int rc = launch_blend_backward(*cam, g, b, img, dL_dcolor, dL_ddepth, grad_acc, s)) return rc;

@@ -90,6 +90,8 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_add_kernel(uint32_t* out, c
         if (base + i < n) out[base + i] += add;
 }
 
+// (Measured and rejected: a single-workgroup scan for small P -- 1024 threads x a serial run of dependent
+//  gathers each -- took ~300 us at P = 38 k against ~15 us for the three launches below: latency, not launches.)
 int launch_scan(const GeometryState& g, int P, hipStream_t s) {
     if (P == 0) return 0;
     const int nb = scan_nblocks(P);
@@ -113,9 +115,17 @@ __global__ void __launch_bounds__(256) duplicate_kernel(int P, const float* __re
                                                         const uint32_t* __restrict__ tiles_touched, uint32_t* keys,
                                                         uint32_t* vals, int gx, int gy, uint32_t r_cap,
                                                         int32_t* __restrict__ n_touched, uint2* __restrict__ ranges,
-                                                        int ntiles) {
+                                                        int ntiles, uint32_t* __restrict__ zero_ptr, size_t zero_words,
+                                                        uint32_t* __restrict__ count, uint32_t* __restrict__ overflow) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
+    grid_zero(zero_ptr, zero_words);                     // scratch of the tile sort that follows (was its own launch)
+    if (i == 0 && count) {                               // capacity mode: live instance count + overflow flag (was a launch)
+        const uint32_t R = P > 0 ? offsets[P - 1] : 0u;
+        count[0] = min(R, r_cap);
+        count[1] = R > r_cap ? 1u : 0u;
+        if (overflow) overflow[0] = count[1];
+    }
     if (i < ntiles) ranges[i] = make_uint2(0u, 0u);      // empty-tile default (was a memset)
     if (i < P) n_touched[i] = 0;                         // (was a memset)
     uint32_t idx = 0, nt = 0, off = 0;
@@ -168,29 +178,19 @@ __global__ void __launch_bounds__(256) duplicate_kernel(int P, const float* __re
     }
 }
 
-__global__ void clamp_count_kernel(const uint32_t* __restrict__ offsets, int P, uint32_t r_cap, uint32_t* count,
-                                   uint32_t* overflow) {
-    const uint32_t R = P > 0 ? offsets[P - 1] : 0u;
-    count[0] = min(R, r_cap);
-    count[1] = R > r_cap ? 1u : 0u;
-    if (overflow) overflow[0] = count[1];          // the caller's flag, written here (no memcpy node in a captured graph)
-}
-
-int launch_clamp_count(const GeometryState& g, int P, uint64_t r_cap, uint32_t* count, uint32_t* overflow, hipStream_t s) {
-    hipLaunchKernelGGL(clamp_count_kernel, dim3(1), dim3(1), 0, s, g.point_offsets, P,
-                       (uint32_t)(r_cap > 0xFFFFFFFFull ? 0xFFFFFFFFull : r_cap), count, overflow);
-    MGS_HIP(hipGetLastError());
-    return 0;
-}
-
 int launch_duplicate(const mgs_camera& cam, int P, const GeometryState& g, const BinningState& b, uint64_t r_cap,
-                     int32_t* n_touched, const ImageState& img, hipStream_t s) {
+                     int32_t* n_touched, const ImageState& img, uint64_t sort_n, int sort_bits, uint32_t* count,
+                     uint32_t* overflow, hipStream_t s) {
     const int ntiles = tiles_x(cam.image_width) * tiles_y(cam.image_height);
     const int n = P > ntiles ? P : ntiles;
     if (n == 0) return 0;
+    uint32_t* zero_ptr = nullptr;
+    size_t zero_words = 0;
+    if (sort_n > 0) radix_zero_region(b.sort_temp, sort_n, sort_bits, &zero_ptr, &zero_words);
     hipLaunchKernelGGL(duplicate_kernel, dim3((n + 255) / 256), dim3(256), 0, s, P, g.rec, g.perm, g.point_offsets,
                        g.tiles_touched, b.keys_a, b.vals_a, tiles_x(cam.image_width), tiles_y(cam.image_height),
-                       (uint32_t)(r_cap > 0xFFFFFFFFull ? 0xFFFFFFFFull : r_cap), n_touched, img.ranges, ntiles);
+                       (uint32_t)(r_cap > 0xFFFFFFFFull ? 0xFFFFFFFFull : r_cap), n_touched, img.ranges, ntiles, zero_ptr,
+                       zero_words, count, overflow);
     MGS_HIP(hipGetLastError());
     return 0;
 }
@@ -201,11 +201,13 @@ int launch_duplicate(const mgs_camera& cam, int P, const GeometryState& g, const
 size_t sort_temp_bytes(uint64_t n, int bits) { return radix_temp_bytes(n, bits); }
 
 int launch_depth_sort(const GeometryState& g, int P, hipStream_t s) {
-    return radix_sort_pairs(g.depth_key, g.iota, g.depth_alt, g.iota_alt, (uint64_t)P, 32, g.sort_temp, s);
+    // the scratch was cleared by preprocess_forward_kernel
+    return radix_sort_pairs(g.depth_key, g.iota, g.depth_alt, g.iota_alt, (uint64_t)P, 32, g.sort_temp, s, nullptr, true);
 }
 
 int launch_sort(const BinningState& b, uint64_t R, int bits, hipStream_t s, const uint32_t* n_dev) {
-    return radix_sort_pairs(b.keys_a, b.vals_a, b.keys_b, b.vals_b, R, bits, b.sort_temp, s, n_dev);
+    // the scratch was cleared by duplicate_kernel
+    return radix_sort_pairs(b.keys_a, b.vals_a, b.keys_b, b.vals_b, R, bits, b.sort_temp, s, n_dev, true);
 }
 
 // ------------------------------------------------------------------------------------------------

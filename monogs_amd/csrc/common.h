@@ -56,6 +56,27 @@ __global__ static void zero_fill_kernel(uint32_t* __restrict__ p, size_t n_words
         for (size_t i = i0; i < n_words; i += stride) p[i] = 0u;
     }
 }
+// the same clear, done by the threads of a kernel that runs anyway (p 16-byte aligned): saves a launch
+__device__ __forceinline__ void grid_zero(uint32_t* __restrict__ p, size_t n_words) {
+    const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+    uint4* q = reinterpret_cast<uint4*>(p);
+    const size_t nv = n_words / 4;
+    for (size_t i = i0; i < nv; i += stride) q[i] = make_uint4(0u, 0u, 0u, 0u);
+    for (size_t i = nv * 4 + i0; i < n_words; i += stride) p[i] = 0u;
+}
+// two regions in one launch (the second one small): gradient accumulator + the 6 pose-gradient floats
+__global__ static void zero_fill2_kernel(uint32_t* __restrict__ p, size_t n_words, uint32_t* __restrict__ p2, int n2) {
+    grid_zero(p, n_words);
+    if (blockIdx.x == 0 && (int)threadIdx.x < n2) p2[threadIdx.x] = 0u;
+}
+static inline hipError_t zero_fill2(void* ptr, size_t bytes, void* ptr2, size_t bytes2, hipStream_t s) {
+    const size_t n_words = bytes / 4;                       // ptr 16-byte aligned; bytes2 <= 1 KiB
+    size_t blocks = (n_words / 4 + 255) / 256;
+    blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
+    hipLaunchKernelGGL(zero_fill2_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (uint32_t*)ptr, n_words,
+                       (uint32_t*)ptr2, ptr2 ? (int)(bytes2 / 4) : 0);
+    return hipGetLastError();
+}
 static inline hipError_t zero_fill(void* ptr, size_t bytes, hipStream_t s) {
     if (bytes == 0) return hipSuccess;
     const size_t n_words = bytes / 4;
@@ -140,15 +161,16 @@ int launch_preprocess_forward(const mgs_camera& cam, int P, const float* means3D
                               const GeometryState& g, int32_t* radii, hipStream_t s);
 int launch_scan(const GeometryState& g, int P, hipStream_t s);
 // `r_cap`: capacity of the binning buffers; `count` (device): [0] live instance count min(R, r_cap), [1] overflow flag
-int launch_clamp_count(const GeometryState& g, int P, uint64_t r_cap, uint32_t* count, uint32_t* overflow, hipStream_t s);
 int launch_duplicate(const mgs_camera& cam, int P, const GeometryState& g, const BinningState& b, uint64_t r_cap,
-                     int32_t* n_touched, const ImageState& img, hipStream_t s);
+                     int32_t* n_touched, const ImageState& img, uint64_t sort_n, int sort_bits, uint32_t* count,
+                     uint32_t* overflow, hipStream_t s);
 size_t sort_temp_bytes(uint64_t n, int bits);
 size_t radix_temp_bytes(uint64_t n, int bits);
 bool radix_result_in_b(int bits);
 const uint32_t* radix_error_flag(void* temp, uint64_t n, int bits);
+void radix_zero_region(void* temp, uint64_t n, int bits, uint32_t** ptr, size_t* words);   // what must be 0 before a sort
 int radix_sort_pairs(uint32_t* ka, uint32_t* va, uint32_t* kb, uint32_t* vb, uint64_t n, int bits, void* temp,
-                     hipStream_t s, const uint32_t* n_dev = nullptr);
+                     hipStream_t s, const uint32_t* n_dev = nullptr, bool temp_zeroed = false);
 int launch_depth_sort(const GeometryState& g, int P, hipStream_t s);
 int launch_sort(const BinningState& b, uint64_t R, int bits, hipStream_t s, const uint32_t* n_dev = nullptr);
 int launch_ranges(const BinningState& b, uint64_t R, const ImageState& img, int ntiles, hipStream_t s,

@@ -21,7 +21,9 @@ namespace mgs {
 constexpr int LS_THREADS = 256;
 constexpr int LS_MAX_BLOCKS = 256;      // forward reduction: two stages, no atomics (64 workgroups were latency-bound: 26 us at VGA)
 // scratch: 16 floats of results followed by LS_MAX_BLOCKS x 8 floats of per-workgroup partial sums
-enum : int { LP_L1_RGB = 6, LP_L1_D = 7, LP_SCALE_RGB = 8, LP_SCALE_D = 9, LP_N = 16, LP_PART = 8 };
+enum : int { LP_L1_RGB = 6, LP_L1_D = 7, LP_SCALE_RGB = 8, LP_SCALE_D = 9, LP_DAB = 10, LP_N = 16, LP_PART = 8 };
+// scratch[LP_DAB .. LP_DAB+1]: left ZERO by the forward; a backward may accumulate d(exposure_a), d(exposure_b) there
+// (d_exposure == scratch + LP_DAB), which saves the launch that clears a separate buffer
 
 struct LossArgs {
     const float *render, *depth, *opacity, *gt_rgb, *gt_depth, *exp_a, *exp_b;
@@ -116,6 +118,8 @@ __global__ void loss_finalize_kernel(LossArgs a, int nblocks, float* __restrict_
         part[LP_L1_D] = l1_d;
         part[LP_SCALE_RGB] = scale_rgb;
         part[LP_SCALE_D] = scale_d;
+        part[LP_DAB] = 0.f;
+        part[LP_DAB + 1] = 0.f;
         loss_out[0] = loss;
     }
 }
@@ -183,7 +187,7 @@ int launch_loss_forward(const LossArgs& a, float* partials, float* loss_out, hip
 
 int launch_loss_backward(const LossArgs& a, const float* partials, const float* grad_out, float* d_render,
                          float* d_depth, float* d_ab, hipStream_t s) {
-    if (d_ab) MGS_HIP(zero_fill(d_ab, 2 * sizeof(float), s));
+    if (d_ab && d_ab != partials + LP_DAB) MGS_HIP(zero_fill(d_ab, 2 * sizeof(float), s));
     hipLaunchKernelGGL(loss_backward_kernel, dim3(loss_grid(a.W, a.H)), dim3(LS_THREADS), 0, s, a, partials, grad_out,
                        d_render, d_depth, d_ab);
     MGS_HIP(hipGetLastError());

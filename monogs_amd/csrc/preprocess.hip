@@ -148,10 +148,13 @@ struct PreArgs {
     int32_t* radii;
     float tanfovx, tanfovy, focal_x, focal_y, mod;
     int P, W, H, gx, gy, deg, M;
+    uint32_t* zero_ptr;       // scratch of the depth sort that follows: cleared here instead of by its own launch
+    size_t zero_words;
 };
 
 __global__ void __launch_bounds__(256) preprocess_forward_kernel(PreArgs a) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    grid_zero(a.zero_ptr, a.zero_words);
     if (idx >= a.P) return;
     a.radii[idx] = 0;
     a.tiles_touched[idx] = 0;
@@ -262,6 +265,7 @@ int launch_preprocess_forward(const mgs_camera& cam, int P, const float* means3D
     a.P = P; a.W = cam.image_width; a.H = cam.image_height;
     a.gx = tiles_x(a.W); a.gy = tiles_y(a.H); a.deg = cam.sh_degree; a.M = cam.sh_coeffs;
     if (P == 0) return 0;
+    radix_zero_region(g.sort_temp, (uint64_t)P, 32, &a.zero_ptr, &a.zero_words);
     hipLaunchKernelGGL(preprocess_forward_kernel, dim3((P + 255) / 256), dim3(256), 0, s, a);
     MGS_HIP(hipGetLastError());
     return 0;

@@ -292,14 +292,22 @@ bool radix_result_in_b(int bits) { return (rs_passes(bits) & 1) != 0; }
 // device word that a timed-out look-back spin sets to 1 (checked by the caller at its next sync point)
 const uint32_t* radix_error_flag(void* temp, uint64_t n, int bits) { return rs_carve(temp, n ? n : 1, bits).error; }
 
+// The region of `temp` that must be zero when the sort starts (histograms, tickets, error flag, status words); a
+// kernel that runs right before the sort can clear it with grid_zero() and pass temp_zeroed = true.
+void radix_zero_region(void* temp, uint64_t n, int bits, uint32_t** ptr, size_t* words) {
+    const RsTemp t = rs_carve(temp, n ? n : 1, bits);
+    *ptr = t.hist;
+    *words = t.zero_bytes / 4;
+}
+
 int radix_sort_pairs(uint32_t* ka, uint32_t* va, uint32_t* kb, uint32_t* vb, uint64_t n, int bits, void* temp,
-                     hipStream_t s, const uint32_t* n_dev) {
+                     hipStream_t s, const uint32_t* n_dev, bool temp_zeroed) {
     if (n == 0) return 0;
     if (n >= (1ull << 32)) { set_error("radix sort: more than 2^32-1 pairs"); return 1; }
     const int npasses = rs_passes(bits);
     if (npasses > RS_MAX_PASSES) { set_error("radix sort: more than 32 key bits"); return 1; }
     const RsTemp t = rs_carve(temp, n, bits);
-    MGS_HIP(zero_fill(t.hist, t.zero_bytes, s));
+    if (!temp_zeroed) MGS_HIP(zero_fill(t.hist, t.zero_bytes, s));
     const uint32_t tiles = rs_tiles(n);
     const uint32_t hist_blocks = min(tiles, 1024u);
     hipLaunchKernelGGL(rs_hist_kernel, dim3(hist_blocks), dim3(RS_THREADS), 0, s, ka, (uint32_t)n, n_dev, npasses, t.hist);

@@ -15,6 +15,9 @@ from . import _lib
 from .rasterizer import _f32, _stream
 
 
+_DAB = 10     # MGS_LOSS_SCRATCH_DAB (include/monogs_raster.h)
+
+
 def _u8(t):
     if t is None:
         return None
@@ -62,14 +65,20 @@ class _FusedLoss(torch.autograd.Function):
             d_render = torch.empty_like(render)
             d_depth = torch.empty_like(depth)
             want_ab = ctx.has_ab and not init and (ctx.needs_input_grad[3] or ctx.needs_input_grad[4])
-            d_ab = torch.empty(2, dtype=torch.float32, device=dev) if want_ab else None
+            d_ab = None
+            if want_ab:
+                if getattr(ctx, "dab_used", False):        # a second backward of the same forward: separate, cleared buffer
+                    d_ab = torch.empty(2, dtype=torch.float32, device=dev)
+                else:                                      # the slot the forward left zeroed (MGS_LOSS_SCRATCH_DAB)
+                    d_ab = scratch[_DAB:_DAB + 2]
+                    ctx.dab_used = True
             _lib.check(lib.mgs_loss_backward(W, H, tracking, init, lam, p(render), p(depth), p(opac, ctx.has_op),
                                              p(gt_rgb), p(gt_depth), p(mask, ctx.has_mask), p(gm, ctx.has_gm),
                                              p(a, ctx.has_ab), p(b, ctx.has_ab), p(scratch), p(go), p(d_render),
                                              p(d_depth), d_ab.data_ptr() if d_ab is not None else None, _stream()),
                        "mgs_loss_backward")
-        d_a = d_ab[0:1].clone() if d_ab is not None else None
-        d_b = d_ab[1:2].clone() if d_ab is not None else None
+        d_a = d_ab[0:1] if d_ab is not None else None      # views: autograd takes them as .grad without a copy kernel
+        d_b = d_ab[1:2] if d_ab is not None else None
         return (d_render, d_depth, None, d_a, d_b, None, None, None, None, None, None, None)
 
 

@@ -246,8 +246,9 @@ class _RasterizeGaussians(torch.autograd.Function):
                 d = timing.as_dict()
                 d.update(kind="backward", num_rendered=ctx.num_rendered, P=P)
                 _timing_sink.append(d)
-        d_theta = d_tau[3:].clone() if (d_tau is not None and need[8] and has_theta) else None
-        d_rho = d_tau[:3].clone() if (d_tau is not None and need[9] and has_rho) else None
+        # (views of the 6-float result: autograd takes them as .grad without a copy kernel)
+        d_theta = d_tau[3:] if (d_tau is not None and need[8] and has_theta) else None
+        d_rho = d_tau[:3] if (d_tau is not None and need[9] and has_rho) else None
         return (d_means3D, d_means2D, d_sh, d_col, d_opac, d_scales, d_rot, d_cov, d_theta, d_rho, None)
 
 

@@ -196,28 +196,54 @@ class TrackingGraph:
         self.flags = [torch.zeros(1, pin_memory=True) for _ in range(2)]
         self.events = [torch.cuda.Event() for _ in range(2)]
         self.graph = None
+        self.one = torch.ones((), device=dev)
         self._load(proto)
         keep = (self.svp.R.clone(), self.svp.T.clone(), self.svp.exposure_a.data.clone(), self.svp.exposure_b.data.clone())
         # eager warm-up on a side stream (also records the capacity hint for this map size), then capture
+        import os, sys, time as _t
+        dbg = os.environ.get("MGS_TRACK_DEBUG") == "1"
+        t0 = _t.perf_counter()
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
-            self._iteration()
+            self._iteration(dbg)
         torch.cuda.current_stream().wait_stream(s)
         self.opt.zero_grad()
+        if dbg:
+            torch.cuda.synchronize(); t1 = _t.perf_counter()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
+            if dbg:
+                t2 = _t.perf_counter()
             self._iteration()
+            if dbg:
+                t3 = _t.perf_counter()
+        if dbg:
+            t4 = _t.perf_counter()
+            print(f"[dbg] warmup {1e3*(t1-t0):.1f} ms, graph enter {1e3*(t2-t1):.1f}, capture body {1e3*(t3-t2):.1f}, "
+                  f"capture end/instantiate {1e3*(t4-t3):.1f}", file=sys.stderr, flush=True)
         with torch.no_grad():          # undo the warm-up step
             self.svp.R.copy_(keep[0]); self.svp.T.copy_(keep[1])
             self.svp.exposure_a.data.copy_(keep[2]); self.svp.exposure_b.data.copy_(keep[3])
 
-    def _iteration(self):
+    def _iteration(self, dbg=False):
+        import sys, time as _t
+        def lap(tag, t=[None]):
+            if dbg:
+                torch.cuda.synchronize(); now = _t.perf_counter()
+                if t[0] is not None:
+                    print(f"[dbg]   {tag}: {1e3 * (now - t[0]):.1f} ms", file=sys.stderr, flush=True)
+                t[0] = now
+        lap("start")
         pkg = render(self.svp, self.intr, *self.map, self.bg)
+        lap("render")
         self.opt.zero_grad()
         loss = fused_losses.get_loss_tracking(pkg["render"], pkg["depth"], pkg["opacity"], self.svp)
-        loss.backward()
+        lap("loss")
+        loss.backward(gradient=self.one)            # a persistent 1.0: no ones_like fill per iteration
+        lap("backward")
         self.opt.step_and_retract(sync=False)
+        lap("pose step")
 
     @torch.no_grad()
     def _load(self, vp: Viewpoint):
@@ -294,7 +320,7 @@ def run_slam(n_frames=12, intrinsics="fr3_office", tracking_itr_num=100, mapping
     bg = torch.zeros(3, device=device)
     gmap = GaussianMap(device, capturable=graph_mapping)
     window: List[Viewpoint] = []
-    stats = dict(track_s=0.0, track_iters=0, tracked=0, map_s=0.0, map_iters=0, keyframes=0, renders=0)
+    stats = dict(track_capture_s=0.0, track_s=0.0, track_iters=0, tracked=0, map_s=0.0, map_iters=0, keyframes=0, renders=0)
 
     def sync():
         torch.cuda.synchronize()
@@ -380,6 +406,7 @@ def run_slam(n_frames=12, intrinsics="fr3_office", tracking_itr_num=100, mapping
             sync(); t0 = time.perf_counter()
             if tgraph is None:                       # the map changed (or first frame): capture against the new map
                 tgraph = TrackingGraph(vp, intr, gmap, bg)
+                sync(); stats["track_capture_s"] += time.perf_counter() - t0
             n_it = tgraph.track(vp, tracking_itr_num, lookahead=track_lookahead)
             sync(); stats["track_s"] += time.perf_counter() - t0
             stats["track_iters"] += n_it

@@ -243,6 +243,7 @@ def main():
                          kf_interval=5, init_itr_num=150, graph_tracking=True, graph_mapping=True)
             slam = {k: (round(v, 3) if isinstance(v, float) else v) for k, v in r.items()
                     if k in ("tracking_fps", "tracking_iters_per_s", "mapping_iters_per_s", "mapping_kf_per_s",
+                             "tracking_steady_iters_per_s", "mapping_steady_iters_per_s", "kf_extend_ms",
                              "ate_rmse_m", "gaussians", "width", "height", "frames", "config", "graph_tracking", "graph_mapping")}
             slam["workload"] = "synthetic TUM-like sequence (fr3_office intrinsics), hipGraph-captured tracking and mapping iterations"
             log("slam", slam)

@@ -196,54 +196,28 @@ class TrackingGraph:
         self.flags = [torch.zeros(1, pin_memory=True) for _ in range(2)]
         self.events = [torch.cuda.Event() for _ in range(2)]
         self.graph = None
-        self.one = torch.ones((), device=dev)
         self._load(proto)
         keep = (self.svp.R.clone(), self.svp.T.clone(), self.svp.exposure_a.data.clone(), self.svp.exposure_b.data.clone())
         # eager warm-up on a side stream (also records the capacity hint for this map size), then capture
-        import os, sys, time as _t
-        dbg = os.environ.get("MGS_TRACK_DEBUG") == "1"
-        t0 = _t.perf_counter()
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
-            self._iteration(dbg)
+            self._iteration()
         torch.cuda.current_stream().wait_stream(s)
         self.opt.zero_grad()
-        if dbg:
-            torch.cuda.synchronize(); t1 = _t.perf_counter()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            if dbg:
-                t2 = _t.perf_counter()
             self._iteration()
-            if dbg:
-                t3 = _t.perf_counter()
-        if dbg:
-            t4 = _t.perf_counter()
-            print(f"[dbg] warmup {1e3*(t1-t0):.1f} ms, graph enter {1e3*(t2-t1):.1f}, capture body {1e3*(t3-t2):.1f}, "
-                  f"capture end/instantiate {1e3*(t4-t3):.1f}", file=sys.stderr, flush=True)
         with torch.no_grad():          # undo the warm-up step
             self.svp.R.copy_(keep[0]); self.svp.T.copy_(keep[1])
             self.svp.exposure_a.data.copy_(keep[2]); self.svp.exposure_b.data.copy_(keep[3])
 
-    def _iteration(self, dbg=False):
-        import sys, time as _t
-        def lap(tag, t=[None]):
-            if dbg:
-                torch.cuda.synchronize(); now = _t.perf_counter()
-                if t[0] is not None:
-                    print(f"[dbg]   {tag}: {1e3 * (now - t[0]):.1f} ms", file=sys.stderr, flush=True)
-                t[0] = now
-        lap("start")
+    def _iteration(self):
         pkg = render(self.svp, self.intr, *self.map, self.bg)
-        lap("render")
         self.opt.zero_grad()
         loss = fused_losses.get_loss_tracking(pkg["render"], pkg["depth"], pkg["opacity"], self.svp)
-        lap("loss")
-        loss.backward(gradient=self.one)            # a persistent 1.0: no ones_like fill per iteration
-        lap("backward")
+        loss.backward()      # (an explicit gradient= tensor costs ~140 ms on its first call and saves one 4 us fill)
         self.opt.step_and_retract(sync=False)
-        lap("pose step")
 
     @torch.no_grad()
     def _load(self, vp: Viewpoint):
@@ -320,7 +294,7 @@ def run_slam(n_frames=12, intrinsics="fr3_office", tracking_itr_num=100, mapping
     bg = torch.zeros(3, device=device)
     gmap = GaussianMap(device, capturable=graph_mapping)
     window: List[Viewpoint] = []
-    stats = dict(track_capture_s=0.0, track_s=0.0, track_iters=0, tracked=0, map_s=0.0, map_iters=0, keyframes=0, renders=0)
+    stats = dict(kf_extend_s=0.0, map_capture_s=0.0, map_replay_s=0.0, map_replay_iters=0, track_capture_s=0.0, track_s=0.0, track_iters=0, tracked=0, map_s=0.0, map_iters=0, keyframes=0, renders=0)
 
     def sync():
         torch.cuda.synchronize()
@@ -350,6 +324,7 @@ def run_slam(n_frames=12, intrinsics="fr3_office", tracking_itr_num=100, mapping
         if graph_mapping and fused_pose_on and fused_losses_on and iters >= 8:
             # two eager iterations on a side stream (Adam state, capacity hints), then capture one and replay
             from . import rasterizer as _r
+            sync(); tc0 = time.perf_counter()
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
@@ -359,8 +334,13 @@ def run_slam(n_frames=12, intrinsics="fr3_office", tracking_itr_num=100, mapping
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 iteration()
+            sync(); tc1 = time.perf_counter()
             for _ in range(iters - 2):
                 graph.replay()
+            sync()
+            stats["map_capture_s"] += tc1 - tc0
+            stats["map_replay_s"] += time.perf_counter() - tc1
+            stats["map_replay_iters"] += iters - 2
             stats["map_iters"] += iters
             stats["renders"] += iters * len(window)
             if _r.check_overflow():
@@ -448,7 +428,9 @@ def run_slam(n_frames=12, intrinsics="fr3_office", tracking_itr_num=100, mapping
             sync(); t0 = time.perf_counter()
             with torch.no_grad():
                 pkg = _render(vp, intr, gmap, bg)
+            sync(); te0 = time.perf_counter()
             gmap.extend_from_frame(vp, intr, downsample=kf_downsample, render_opacity=pkg["opacity"], point_size=point_size)
+            sync(); stats["kf_extend_s"] += time.perf_counter() - te0
             window.append(vp)
             if len(window) > window_size:
                 window.pop(1)
@@ -474,6 +456,12 @@ def run_slam(n_frames=12, intrinsics="fr3_office", tracking_itr_num=100, mapping
                tracking_iters_per_s=stats["track_iters"] / max(stats["track_s"], 1e-9),
                mapping_iters_per_s=stats["map_iters"] / max(stats["map_s"], 1e-9),
                mapping_kf_per_s=stats["keyframes"] / max(stats["map_s"], 1e-9),
+               # steady state: graph replays only (no capture, no keyframe insertion, no one-time lazy loading)
+               tracking_steady_iters_per_s=(stats["track_iters"] / max(stats["track_s"] - stats["track_capture_s"], 1e-9)
+                                            if graph_tracking else None),
+               mapping_steady_iters_per_s=(stats["map_replay_iters"] / max(stats["map_replay_s"], 1e-9)
+                                           if stats["map_replay_iters"] else None),
+               kf_extend_ms=1e3 * stats["kf_extend_s"] / max(stats["keyframes"] - 1, 1),
                ate_rmse_m=float(torch.sqrt((err ** 2).mean())),
                fused_losses=bool(fused_losses_on), fused_pose=bool(fused_pose_on), graph_tracking=bool(graph_tracking), graph_mapping=bool(graph_mapping),
                config=dict(tracking_itr_num=tracking_itr_num, mapping_itr_num=mapping_itr_num,

@@ -190,6 +190,18 @@ int mgs_pose_step(float* R, float* T, float* rot_delta, float* trans_delta, floa
                   float beta1, float beta2, float eps, float converged_threshold, int32_t* step_counter, float* out,
                   int32_t flags, void* stream);
 
+/* ---- Keyframe back-projection ------------------------------------------------
+ * The per-point part of GaussianModel.create_viewpoint_pcd (/root/reference/gaussian_splatting/scene/gaussian_model.py:121-319)
+ * for N selected pixels: gather rgb (with the tracked exposure exp(a)*rgb + b clamped to [0,1] when exposure_a is
+ * non-NULL) and depth, unproject the pixel centre (x+0.5, y+0.5) with (fx, fy, cx, cy) and move it to the world
+ * with the world->camera pose (R row-major, T): p_w = R^T (p_c - T).  selected[i] = x * H + y (the reference's
+ * flattening order, gaussian_model.py:180-187).  segmentation / ids may be NULL. */
+int mgs_backproject(int32_t N, int32_t W, int32_t H, const int64_t* selected, const float* rgb /* [3,H,W] */,
+                    const float* depth /* [H,W] */, const int32_t* segmentation /* [H,W] or NULL */,
+                    const float* exposure_a, const float* exposure_b, float fx, float fy, float cx, float cy,
+                    const float* R, const float* T, float* points /* [N,3] */, float* features /* [N,3] */,
+                    int32_t* ids /* [N] or NULL */, void* stream);
+
 /* ---- Camera matrices of one viewpoint ---------------------------------
  * From the world->camera rotation R[3,3] (row-major) and translation T[3] and the transposed projection
  * projmatrix_raw[4,4]: viewmatrix = getWorld2View(R, T)^T (/root/reference/gaussian_splatting/utils/graphics_utils.py:33-42,

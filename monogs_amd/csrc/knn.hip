@@ -288,3 +288,55 @@ int launch_knn(int P, const float* points, float* out, void* scratch, hipStream_
 }
 
 }  // namespace mgs
+
+// ------------------------------------------------------------------------------------------------
+// Keyframe back-projection: the gather + exposure + unprojection + camera->world
+// part of GaussianModel.create_viewpoint_pcd (/root/reference/gaussian_splatting/scene/gaussian_model.py:121-319)
+// for the N selected pixels, one launch.  `sel` indexes pixels in the reference's flattening order
+// (x outer, y inner: i = x * H + y, gaussian_model.py:180-187,221-233); the pixel centre is (x + 0.5, y + 0.5).
+// ------------------------------------------------------------------------------------------------
+namespace mgs {
+
+__global__ void __launch_bounds__(256) backproject_kernel(int N, int W, int H, const int64_t* __restrict__ sel,
+                                                          const float* __restrict__ rgb, const float* __restrict__ depth,
+                                                          const int32_t* __restrict__ seg, const float* __restrict__ exp_a,
+                                                          const float* __restrict__ exp_b, float fx, float fy, float cx,
+                                                          float cy, const float* __restrict__ R, const float* __restrict__ T,
+                                                          float* __restrict__ pts, float* __restrict__ feat,
+                                                          int32_t* __restrict__ ids) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const int64_t s = sel[i];
+    const int x = (int)(s / H), y = (int)(s % H);
+    const size_t pix = (size_t)y * W + x, HW = (size_t)H * W;
+    const float z = depth[pix];
+    const float xc = ((float)x + 0.5f - cx) / fx * z, yc = ((float)y + 0.5f - cy) / fy * z;
+    const float dx = xc - T[0], dy = yc - T[1], dz = z - T[2];          // p_w = R^T (p_c - t)
+    pts[3 * i] = R[0] * dx + R[3] * dy + R[6] * dz;
+    pts[3 * i + 1] = R[1] * dx + R[4] * dy + R[7] * dz;
+    pts[3 * i + 2] = R[2] * dx + R[5] * dy + R[8] * dz;
+    float c0 = rgb[pix], c1 = rgb[HW + pix], c2 = rgb[2 * HW + pix];
+    if (exp_a) {                                                        // exposure learned during tracking, clamped to [0, 1]
+        const float ea = expf(exp_a[0]), eb = exp_b ? exp_b[0] : 0.f;
+        c0 = fminf(fmaxf(ea * c0 + eb, 0.f), 1.f);
+        c1 = fminf(fmaxf(ea * c1 + eb, 0.f), 1.f);
+        c2 = fminf(fmaxf(ea * c2 + eb, 0.f), 1.f);
+    }
+    feat[3 * i] = c0; feat[3 * i + 1] = c1; feat[3 * i + 2] = c2;
+    if (ids) ids[i] = seg ? seg[pix] : 0;
+}
+
+}  // namespace mgs
+
+extern "C" int mgs_backproject(int32_t N, int32_t W, int32_t H, const int64_t* selected, const float* rgb,
+                               const float* depth, const int32_t* segmentation, const float* exposure_a,
+                               const float* exposure_b, float fx, float fy, float cx, float cy, const float* R,
+                               const float* T, float* points, float* features, int32_t* ids, void* stream) {
+    if (N < 0 || W <= 0 || H <= 0) { mgs::set_error("mgs_backproject: bad sizes"); return 1; }
+    if (N == 0) return 0;
+    if (!selected || !rgb || !depth || !R || !T || !points || !features) { mgs::set_error("mgs_backproject: NULL argument"); return 1; }
+    hipLaunchKernelGGL(mgs::backproject_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, W, H, selected,
+                       rgb, depth, segmentation, exposure_a, exposure_b, fx, fy, cx, cy, R, T, points, features, ids);
+    MGS_HIP(hipGetLastError());
+    return 0;
+}

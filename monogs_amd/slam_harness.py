@@ -37,6 +37,7 @@ class Intrinsics:
     def __init__(self, k: dict, device):
         self.k, self.device = dict(k), device
         self.height, self.width = k["H"], k["W"]
+        self.fx, self.fy, self.cx, self.cy = k["fx"], k["fy"], k["cx"], k["cy"]
         m = cam.camera_matrices(torch.eye(3), torch.zeros(3), k["fx"], k["fy"], k["cx"], k["cy"], k["W"], k["H"])
         self.projection_matrix = m.projmatrix_raw.to(device)        # transposed, as the reference's property
         self.FoVx, self.FoVy = 2 * math.atan(m.tanfovx), 2 * math.atan(m.tanfovy)
@@ -111,26 +112,14 @@ class GaussianMap:
                           render_opacity=None):
         """Back-project a keyframe's depth into new Gaussians; scale from distCUDA2
         (/root/reference/gaussian_splatting/scene/gaussian_model.py:121-319, simplified)."""
-        H, W, k = intr.height, intr.width, intr.k
-        valid = vp.depth > 0
-        if render_opacity is not None and not init:
-            valid = valid & (render_opacity[0] < 0.5)
-        idx = valid.reshape(-1).nonzero().squeeze(1)
-        g = torch.Generator(device="cpu").manual_seed(1000 + vp.frame_idx)
-        keep = torch.randperm(idx.numel(), generator=g)[: max(idx.numel() // downsample, 0)].to(self.device)
-        idx = idx[keep]
-        if idx.numel() < 4:
+        from .keyframe import create_viewpoint_pcd
+        g = torch.Generator(device=self.device).manual_seed(1000 + vp.frame_idx)
+        pw, rgb, scales, rots, opac, _ = create_viewpoint_pcd(
+            vp, intr, render_depth=None if init else vp.depth, render_opacity=None if init else render_opacity, init=init,
+            generator=g, downsample_factor=downsample, point_size=1e9, point_size_max=point_size)   # scale^2 = dist2 * point_size
+        n_new = pw.shape[0]
+        if n_new < 4:
             return 0
-        v, u = idx // W, idx % W
-        z = vp.depth.reshape(-1)[idx]
-        pc = torch.stack([(u.float() - k["cx"]) / k["fx"] * z, (v.float() - k["cy"]) / k["fy"] * z, z], dim=1)
-        pw = (pc - vp.T[None]) @ vp.R                     # R^T (p_c - t)
-        rgb = vp.rgb.reshape(3, -1)[:, idx].t().contiguous()
-        dist2 = torch.clamp_min(distCUDA2(pw.contiguous()), 1e-7) * point_size
-        scales = torch.log(torch.sqrt(dist2))[:, None]
-        rots = torch.zeros(idx.numel(), 4, device=self.device)
-        rots[:, 0] = 1
-        opac = torch.zeros(idx.numel(), 1, device=self.device)      # inverse_sigmoid(0.5)
         new = [pw, rgb, opac, scales, rots]
         old_opt = self.optimizer
         old_state = old_opt.state_dict()["state"] if (old_opt is not None and not self.fused_adam) else {}
@@ -145,7 +134,7 @@ class GaussianMap:
                     self.optimizer.exp_avg[i][:n_old] = old_opt.exp_avg[i]
                     self.optimizer.exp_avg_sq[i][:n_old] = old_opt.exp_avg_sq[i]
                 self.optimizer.t_dev.copy_(old_opt.t_dev)
-            return idx.numel()
+            return n_new
         groups = [{"params": [p], "lr": lr} for p, lr in zip(self.params(), lrs)]
         try:       # one multi-tensor kernel per step (the reference uses the default, unfused Adam)
             self.optimizer = torch.optim.Adam(groups, eps=1e-15, fused=True, capturable=self.capturable)
@@ -159,7 +148,7 @@ class GaussianMap:
                 pad = lambda t: torch.cat([t, torch.zeros(n_new, *t.shape[1:], device=self.device)], 0)  # noqa: E731
                 self.optimizer.state[p] = dict(step=st["step"], exp_avg=pad(st["exp_avg"]),
                                                exp_avg_sq=pad(st["exp_avg_sq"]))
-        return idx.numel()
+        return n_new
 
 
 def _render(vp, intr, gmap: GaussianMap, bg):

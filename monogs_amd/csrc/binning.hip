@@ -23,14 +23,7 @@ namespace mgs {
 constexpr int SCAN_THREADS = 256;
 constexpr int SCAN_PER_THREAD = SCAN_ITEMS / SCAN_THREADS;
 
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t n = __shfl_up(v, o, 64);
-        if (lane >= o) v += n;
-    }
-    return v;
-}
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int) { return wave_incl_scan_dpp(v); }
 
 // block-wide exclusive prefix of one value per thread; returns the prefix, writes the total
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t& total, uint32_t* smem /* >=5 */) {

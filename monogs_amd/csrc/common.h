@@ -40,6 +40,20 @@ enum : int {
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// ---- 64-lane inclusive scan (u32 add) on the DPP data path: 4 row shifts + 2 row broadcasts, ~60 cycles, instead of
+// six __shfl_up round trips through ds_bpermute (the LDS crossbar, >100 cycles each).
+__device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t v) {
+#define MGS_DPP_ADD(ctrl, row_mask) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, row_mask, 0xf, false)
+    MGS_DPP_ADD(0x111, 0xf);      // row_shr:1
+    MGS_DPP_ADD(0x112, 0xf);      // row_shr:2
+    MGS_DPP_ADD(0x114, 0xf);      // row_shr:4
+    MGS_DPP_ADD(0x118, 0xf);      // row_shr:8   -> inclusive within each row of 16
+    MGS_DPP_ADD(0x142, 0xa);      // row_bcast:15 into rows 1, 3
+    MGS_DPP_ADD(0x143, 0xc);      // row_bcast:31 into rows 2, 3
+#undef MGS_DPP_ADD
+    return v;
+}
+
 // ---- zero fill as a plain kernel ------------------------------------------------------------
 // Every clear on the hot path is a kernel, never hipMemsetAsync / hipMemcpyAsync: inside a captured hipGraph
 // those become memset / memcpy NODES, and on this ROCm a graph holding them faulted ("write access to a

@@ -20,6 +20,8 @@
 // bounded and raises an error flag instead of hanging.
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace mgs {
 
 constexpr int RS_THREADS = 256;
@@ -41,6 +43,12 @@ constexpr uint64_t RS_COUNT_MASK = (1ull << 62) - 1;
 constexpr uint32_t RS_SPIN_LIMIT = 1u << 22;
 constexpr int RS_WINDOW = 16;                     // predecessor status words fetched per look-back step
 
+// large sorts take the SCANNED path (rs_pass_kernel); MGS_RADIX_SCANNED=0/1 forces one for experiments / tests
+static inline bool rs_scanned(uint64_t n) {
+    const char* e = getenv("MGS_RADIX_SCANNED");
+    if (e && (e[0] == '0' || e[0] == '1')) return e[0] == '1' && rs_items(n) == RS_ITEMS;
+    return rs_items(n) == RS_ITEMS;          // > 1 M pairs: hundreds of tiles
+}
 static inline int rs_passes(int bits) { return (bits + 7) / 8; }
 static inline uint32_t rs_tiles(uint64_t n) {
     const uint64_t tile = (uint64_t)RS_THREADS * rs_items(n);
@@ -102,6 +110,74 @@ __global__ void __launch_bounds__(RS_THREADS) rs_hist_kernel(const uint32_t* __r
     }
 }
 
+// ---- SCANNED path, step 1: digit counts of every tile for one pass, counts[digit][tile] -----------------------
+template <int ITEMS>
+__global__ void __launch_bounds__(RS_THREADS) rs_tile_hist_kernel(const uint32_t* __restrict__ keys, uint32_t n,
+                                                                  const uint32_t* __restrict__ n_dev, int shift,
+                                                                  uint32_t tiles, uint32_t* __restrict__ counts) {
+    constexpr uint32_t TILE_PAIRS = RS_THREADS * ITEMS;
+    __shared__ uint32_t wh[RS_WAVES][RS_RADIX];
+    const int t = threadIdx.x, wv = t >> 6;
+    for (int i = t; i < RS_WAVES * RS_RADIX; i += RS_THREADS) (&wh[0][0])[i] = 0;
+    __syncthreads();
+    const uint32_t n_live = n_dev ? min(n, n_dev[0]) : n;
+    const uint32_t tile = blockIdx.x, tile_start = tile * TILE_PAIRS;
+    if (tile_start < n_live) {
+        const uint32_t tile_n = min(TILE_PAIRS, n_live - tile_start);
+        uint32_t k[ITEMS];
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {
+            const uint32_t e = (uint32_t)i * RS_THREADS + t;
+            k[i] = e < tile_n ? keys[tile_start + e] : 0u;
+        }
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i)
+            if ((uint32_t)i * RS_THREADS + t < tile_n) atomicAdd(&wh[wv][(k[i] >> shift) & 0xFFu], 1u);
+    }
+    __syncthreads();
+    counts[(size_t)t * tiles + tile] = (wh[0][t] + wh[1][t]) + (wh[2][t] + wh[3][t]);     // dead tiles write zeros
+}
+
+// ---- SCANNED path, step 2: counts[digit][tile] -> exclusive scan along the tiles of each digit, plus the global base
+// of every digit.  One wave per digit: lane l sums a contiguous segment of the row, ONE 64-lane scan joins the
+// segments (a scan per 64-element chunk went through ds_bpermute 7 times per chunk: 8.7 us for 125 k counts).  The
+// row totals go to `totals`; the last workgroup to finish (atomic ticket, no waiting) scans the 256 totals into
+// `base`, which the scatter kernel adds.  That replaces the separate all-pass histogram kernel.
+__global__ void __launch_bounds__(RS_THREADS) rs_row_scan_kernel(uint32_t* __restrict__ counts, uint32_t tiles,
+                                                                 uint32_t* __restrict__ totals /* [256] */,
+                                                                 uint32_t* __restrict__ base /* [256] */,
+                                                                 uint32_t* __restrict__ ticket) {
+    __shared__ uint32_t s_last;
+    __shared__ uint32_t s_w[RS_WAVES];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const uint32_t d = blockIdx.x * RS_WAVES + wv;                          // 0..255
+    uint32_t* row = counts + (size_t)d * tiles;
+    uint32_t carry = 0;                                                     // wave-uniform
+    uint32_t next = lane < tiles ? row[lane] : 0u;                          // one chunk in flight ahead of the scan
+    for (uint32_t b0 = 0; b0 < tiles; b0 += WAVE) {
+        const uint32_t i = b0 + lane;
+        const uint32_t v = next;
+        next = (i + WAVE) < tiles ? row[i + WAVE] : 0u;
+        const uint32_t incl = wave_incl_scan_dpp(v);
+        if (i < tiles) row[i] = carry + incl - v;
+        carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    }
+    if (lane == 0) __hip_atomic_store(totals + d, carry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence();
+    __syncthreads();
+    if (t == 0) s_last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+    __syncthreads();
+    if (!s_last) return;
+    // last workgroup: every row total has been published (release above, agent-scope loads here)
+    const uint32_t tot = __hip_atomic_load(totals + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t ti = wave_incl_scan_dpp(tot);
+    if (lane == 63) s_w[wv] = ti;
+    __syncthreads();
+    uint32_t add = 0;
+    for (int w = 0; w < wv; ++w) add += s_w[w];
+    base[t] = add + ti - tot;
+}
+
 struct RsPassArgs {
     const uint32_t* kin;
     uint32_t* kout;
@@ -110,13 +186,21 @@ struct RsPassArgs {
     uint32_t n;               // number of pairs (capacity when n_dev is set)
     const uint32_t* n_dev;    // optional: live count on the device (<= n after clamping)
     int shift;
-    const uint32_t* hist;     // [256] global count of each digit for this pass
+    const uint32_t* hist;     // [256] global count of each digit for this pass (SCANNED path: global BASE of each digit)
     uint64_t* status;         // [tiles][256]
     uint32_t* ticket;
     uint32_t* error;
+    const uint32_t* scanned;  // SCANNED path: [256][tiles] exclusive scan (digit-major) of the per-tile digit counts
+    uint32_t tiles;
 };
 
-template <int ITEMS>
+// SCANNED = false: one sweep -- the tile publishes its digit counts and finds the sum over earlier tiles by decoupled
+//                  look-back (fewest launches: right for the small sorts of SLAM-sized maps).
+// SCANNED = true:  the global position of every (digit, tile) run was computed beforehand by rs_tile_hist_kernel +
+//                  rs_scan_kernel.  With several hundred co-resident tiles starting together the look-back reads
+//                  ~tiles^2/2 x 256 status words per pass -- more L2 traffic than the keys -- and its chain of
+//                  round trips, not the data movement, set the pass time (35 us for 32 MB at 2 M pairs).
+template <int ITEMS, bool SCANNED>
 __global__ void __launch_bounds__(RS_THREADS) rs_pass_kernel(RsPassArgs a) {
     constexpr int TILE_PAIRS = RS_THREADS * ITEMS;
     __shared__ uint32_t wave_hist[RS_WAVES][RS_RADIX];
@@ -128,7 +212,7 @@ __global__ void __launch_bounds__(RS_THREADS) rs_pass_kernel(RsPassArgs a) {
     __shared__ uint32_t s_tile;
 
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    if (t == 0) s_tile = a.ticket ? atomicAdd(a.ticket, 1u) : blockIdx.x;   // a returning atomic is a ~2 us round trip
+    if (t == 0) s_tile = (!SCANNED && a.ticket) ? atomicAdd(a.ticket, 1u) : blockIdx.x;   // a returning atomic is a ~2 us round trip
     for (int i = t; i < RS_WAVES * RS_RADIX; i += RS_THREADS) (&wave_hist[0][0])[i] = 0;
     __syncthreads();
     const uint32_t tile = s_tile;
@@ -181,82 +265,78 @@ __global__ void __launch_bounds__(RS_THREADS) rs_pass_kernel(RsPassArgs a) {
         }
         total = run;
     }
-    uint32_t incl = total;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t u = __shfl_up(incl, o, 64);
-        if (lane >= o) incl += u;
-    }
+    const uint32_t incl = wave_incl_scan_dpp(total);
     if (lane == 63) wsum[wv] = incl;
     __syncthreads();
     uint32_t wadd = 0;
     for (int w = 0; w < wv; ++w) wadd += wsum[w];
     const uint32_t dbase = wadd + incl - total;
     digit_base[t] = dbase;
-    // exclusive global base of digit t = scan of this pass's global histogram (256 values: cheaper here
-    // than a separate launch between the histogram and the first pass)
-    const uint32_t hcount = a.hist[t];
-    uint32_t hincl = hcount;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t u = __shfl_up(hincl, o, 64);
-        if (lane >= o) hincl += u;
-    }
-    __syncthreads();                     // wsum is reused
-    if (lane == 63) wsum[wv] = hincl;
-    __syncthreads();
-    uint32_t hadd = 0;
-    for (int w = 0; w < wv; ++w) hadd += wsum[w];
-    const uint32_t gdigit_base = hadd + hincl - hcount;
-
-    // ---- publish, look back, publish (one digit per thread)
-    uint64_t* my = a.status + (size_t)tile * RS_RADIX + t;
-    uint64_t prefix = 0;
-    if (tile == 0) {
-        __hip_atomic_store(my, RS_FLAG_GLOBAL | (uint64_t)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (SCANNED) {
+        // absolute position of this tile's run of digit t, straight from the scanned table
+        gbase[t] = (int64_t)a.hist[t] + (int64_t)a.scanned[(size_t)t * a.tiles + tile] - (int64_t)dbase;
+        __syncthreads();
     } else {
-        __hip_atomic_store(my, RS_FLAG_LOCAL | (uint64_t)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // Batched look-back: RS_WINDOW predecessor words are requested at once (independent loads, one
-        // memory latency), then consumed nearest-first.  With every resident tile starting together the
-        // serial walk costs ~sqrt(2*tiles) dependent round trips; the window divides that by RS_WINDOW.
-        int64_t j = (int64_t)tile - 1;
-        bool found = false;
-        uint32_t spins = 0;
-        while (!found) {
-            uint64_t w[RS_WINDOW];
+        // exclusive global base of digit t = scan of this pass's global histogram (256 values: cheaper here
+        // than a separate launch between the histogram and the first pass)
+        const uint32_t hcount = a.hist[t];
+        const uint32_t hincl = wave_incl_scan_dpp(hcount);
+        __syncthreads();                     // wsum is reused
+        if (lane == 63) wsum[wv] = hincl;
+        __syncthreads();
+        uint32_t hadd = 0;
+        for (int w = 0; w < wv; ++w) hadd += wsum[w];
+        const uint32_t gdigit_base = hadd + hincl - hcount;
+
+        // ---- publish, look back, publish (one digit per thread)
+        uint64_t* my = a.status + (size_t)tile * RS_RADIX + t;
+        uint64_t prefix = 0;
+        if (tile == 0) {
+            __hip_atomic_store(my, RS_FLAG_GLOBAL | (uint64_t)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            __hip_atomic_store(my, RS_FLAG_LOCAL | (uint64_t)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // Batched look-back: RS_WINDOW predecessor words are requested at once (independent loads, one
+            // memory latency), then consumed nearest-first.  With every resident tile starting together the
+            // serial walk costs ~sqrt(2*tiles) dependent round trips; the window divides that by RS_WINDOW.
+            int64_t j = (int64_t)tile - 1;
+            bool found = false;
+            uint32_t spins = 0;
+            while (!found) {
+                uint64_t w[RS_WINDOW];
 #pragma unroll
-            for (int q = 0; q < RS_WINDOW; ++q) {
-                const int64_t jj = j - q;
-                w[q] = jj >= 0 ? __hip_atomic_load(a.status + (size_t)jj * RS_RADIX + t, __ATOMIC_RELAXED,
-                                                   __HIP_MEMORY_SCOPE_AGENT)
-                               : RS_FLAG_GLOBAL;              // virtual tile -1: inclusive count 0
-            }
-            int used = 0;
+                for (int q = 0; q < RS_WINDOW; ++q) {
+                    const int64_t jj = j - q;
+                    w[q] = jj >= 0 ? __hip_atomic_load(a.status + (size_t)jj * RS_RADIX + t, __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_AGENT)
+                                   : RS_FLAG_GLOBAL;              // virtual tile -1: inclusive count 0
+                }
+                int used = 0;
 #pragma unroll
-            for (int q = 0; q < RS_WINDOW; ++q) {
-                if (!found && used == q) {
-                    const uint64_t f = w[q] >> 62;
-                    if (f != 0ull) {
-                        prefix += w[q] & RS_COUNT_MASK;
-                        ++used;
-                        found = (f != 1ull);
+                for (int q = 0; q < RS_WINDOW; ++q) {
+                    if (!found && used == q) {
+                        const uint64_t f = w[q] >> 62;
+                        if (f != 0ull) {
+                            prefix += w[q] & RS_COUNT_MASK;
+                            ++used;
+                            found = (f != 1ull);
+                        }
                     }
                 }
-            }
-            j -= used;
-            if (!found && used == 0) {                       // nearest predecessor not published yet
-                if (++spins > RS_SPIN_LIMIT) {
-                    atomicExch(a.error, 1u);
-                    break;
+                j -= used;
+                if (!found && used == 0) {                       // nearest predecessor not published yet
+                    if (++spins > RS_SPIN_LIMIT) {
+                        atomicExch(a.error, 1u);
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
                 }
-                __builtin_amdgcn_s_sleep(1);
             }
+            __hip_atomic_store(my, RS_FLAG_GLOBAL | (prefix + (uint64_t)total), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
         }
-        __hip_atomic_store(my, RS_FLAG_GLOBAL | (prefix + (uint64_t)total), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
+        gbase[t] = (int64_t)gdigit_base + (int64_t)prefix - (int64_t)dbase;
+        __syncthreads();
     }
-    gbase[t] = (int64_t)gdigit_base + (int64_t)prefix - (int64_t)dbase;
-    __syncthreads();
 
     // ---- lay the tile out digit by digit in LDS (stable), then stream each run to its final place
 #pragma unroll
@@ -310,7 +390,10 @@ int radix_sort_pairs(uint32_t* ka, uint32_t* va, uint32_t* kb, uint32_t* vb, uin
     if (!temp_zeroed) MGS_HIP(zero_fill(t.hist, t.zero_bytes, s));
     const uint32_t tiles = rs_tiles(n);
     const uint32_t hist_blocks = min(tiles, 1024u);
-    hipLaunchKernelGGL(rs_hist_kernel, dim3(hist_blocks), dim3(RS_THREADS), 0, s, ka, (uint32_t)n, n_dev, npasses, t.hist);
+    const bool scanned = rs_scanned(n);
+    if (!scanned)
+        hipLaunchKernelGGL(rs_hist_kernel, dim3(hist_blocks), dim3(RS_THREADS), 0, s, ka, (uint32_t)n, n_dev, npasses, t.hist);
+    uint32_t* counts = reinterpret_cast<uint32_t*>(t.status);      // the status words are unused on the SCANNED path
     uint32_t *kin = ka, *vin = va, *kout = kb, *vout = vb;
     for (int p = 0; p < npasses; ++p) {
         RsPassArgs a;
@@ -321,12 +404,20 @@ int radix_sort_pairs(uint32_t* ka, uint32_t* va, uint32_t* kb, uint32_t* vb, uin
         // <= one workgroup per CU: the whole grid is co-resident whatever the dispatch order, so block ids are safe
         a.ticket = tiles <= 256u ? nullptr : t.tickets + p;
         a.error = t.error;
-        if (rs_items(n) == RS_ITEMS_SMALL)
-            hipLaunchKernelGGL(rs_pass_kernel<RS_ITEMS_SMALL>, dim3(tiles), dim3(RS_THREADS), 0, s, a);
+        a.scanned = counts; a.tiles = tiles;
+        if (scanned) {
+            // t.hist[p] receives the digit bases, t.base[p] the row totals, t.tickets[p] counts finished workgroups
+            hipLaunchKernelGGL(rs_tile_hist_kernel<RS_ITEMS>, dim3(tiles), dim3(RS_THREADS), 0, s, kin, (uint32_t)n, n_dev,
+                               a.shift, tiles, counts);
+            hipLaunchKernelGGL(rs_row_scan_kernel, dim3(RS_RADIX / RS_WAVES), dim3(RS_THREADS), 0, s, counts, tiles,
+                               t.base + p * RS_RADIX, t.hist + p * RS_RADIX, t.tickets + p);
+            hipLaunchKernelGGL((rs_pass_kernel<RS_ITEMS, true>), dim3(tiles), dim3(RS_THREADS), 0, s, a);
+        } else if (rs_items(n) == RS_ITEMS_SMALL)
+            hipLaunchKernelGGL((rs_pass_kernel<RS_ITEMS_SMALL, false>), dim3(tiles), dim3(RS_THREADS), 0, s, a);
         else if (rs_items(n) == RS_ITEMS_MID)
-            hipLaunchKernelGGL(rs_pass_kernel<RS_ITEMS_MID>, dim3(tiles), dim3(RS_THREADS), 0, s, a);
+            hipLaunchKernelGGL((rs_pass_kernel<RS_ITEMS_MID, false>), dim3(tiles), dim3(RS_THREADS), 0, s, a);
         else
-            hipLaunchKernelGGL(rs_pass_kernel<RS_ITEMS>, dim3(tiles), dim3(RS_THREADS), 0, s, a);
+            hipLaunchKernelGGL((rs_pass_kernel<RS_ITEMS, false>), dim3(tiles), dim3(RS_THREADS), 0, s, a);
         uint32_t* tk = kin; kin = kout; kout = tk;
         uint32_t* tv = vin; vin = vout; vout = tv;
     }

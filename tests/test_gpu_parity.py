@@ -148,7 +148,7 @@ def test_knn(native_lib):
     assert torch.allclose(got, dist2_knn(pts), rtol=1e-5, atol=1e-9)
 
 
-def test_c5_full_size_properties(native_lib):
+def test_c5_full_size_properties(native_lib, monkeypatch):
     """BASELINE config 5 (2 M Gaussians, 1920x1080) is too large for the oracle, so it is checked through
     size-independent properties: the tile lists partition [0, R) and are sorted by (tile, depth bits, index),
     the image invariants hold, the forward is bitwise repeatable, and the backward is linear in the upstream
@@ -186,6 +186,12 @@ def test_c5_full_size_properties(native_lib):
     t2 = forward_tables(st, dev(sc.means3D), dev(sc.opacities), **args)
     assert torch.equal(t["color"], t2["color"]) and torch.equal(t["point_list"], t2["point_list"])
     assert torch.equal(t["n_touched"], t2["n_touched"])
+    # the two radix-sort paths (pre-scanned offsets, the default at this size, and one-sweep look-back) agree bit for bit
+    monkeypatch.setenv("MGS_RADIX_SCANNED", "0")
+    t3 = forward_tables(st, dev(sc.means3D), dev(sc.opacities), **args)
+    monkeypatch.delenv("MGS_RADIX_SCANNED")
+    assert torch.equal(t["point_list"], t3["point_list"]) and torch.equal(t["ranges"], t3["ranges"])
+    assert torch.equal(t["color"], t3["color"])
     # backward: linear in the upstream gradient
     def grads(scale):
         m = dev(sc.means3D).clone().requires_grad_(True)

@@ -36,6 +36,8 @@ GeometryState GeometryState::carve(void* base, int P) {
     g.point_offsets = (uint32_t*)take(p, (size_t)P * sizeof(uint32_t));
     g.scan_blocks = (uint32_t*)take(p, ((size_t)scan_nblocks(P) + 64) * sizeof(uint32_t));
     g.clamped = (uint8_t*)take(p, (size_t)P * 4);
+    g.rect = (uint2*)take(p, (size_t)P * sizeof(uint2));
+    g.rect_sorted = (uint2*)take(p, (size_t)P * sizeof(uint2));
     g.sort_temp_bytes = mgs::sort_temp_bytes((uint64_t)P, 32);
     g.sort_temp = take(p, g.sort_temp_bytes);
     g.end = p;

@@ -38,9 +38,8 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t& total,
     return base + incl - v;
 }
 
-// out[i] = inclusive sum of in[perm[j]], j <= i  (perm = depth order of the Gaussians)
-__global__ void __launch_bounds__(SCAN_THREADS) scan_local_kernel(const uint32_t* __restrict__ in,
-                                                                  const uint32_t* __restrict__ perm, uint32_t* out,
+// out[i] = inclusive sum of the tiles touched by the Gaussians j <= i in depth order (rects = rect_sorted)
+__global__ void __launch_bounds__(SCAN_THREADS) scan_local_kernel(const uint2* __restrict__ rects, uint32_t* out,
                                                                   uint32_t* block_sums, int n) {
     __shared__ uint32_t smem[8];
     const int base = blockIdx.x * SCAN_ITEMS + threadIdx.x * SCAN_PER_THREAD;
@@ -48,7 +47,8 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_local_kernel(const uint32_t
     uint32_t sum = 0;
 #pragma unroll
     for (int i = 0; i < SCAN_PER_THREAD; ++i) {
-        v[i] = (base + i < n) ? in[perm[base + i]] : 0u;
+        const uint32_t wh = (base + i < n) ? rects[base + i].y : 0u;      // tiles touched = w * h of the rectangle
+        v[i] = (wh & 0xFFFFu) * (wh >> 16);
         sum += v[i];
     }
     uint32_t total;
@@ -88,8 +88,8 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_add_kernel(uint32_t* out, c
 int launch_scan(const GeometryState& g, int P, hipStream_t s) {
     if (P == 0) return 0;
     const int nb = scan_nblocks(P);
-    hipLaunchKernelGGL(scan_local_kernel, dim3(nb), dim3(SCAN_THREADS), 0, s, g.tiles_touched, g.perm,
-                       g.point_offsets, g.scan_blocks, P);
+    hipLaunchKernelGGL(scan_local_kernel, dim3(nb), dim3(SCAN_THREADS), 0, s, g.rect_sorted, g.point_offsets,
+                       g.scan_blocks, P);
     if (nb > 1) {
         hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(SCAN_THREADS), 0, s, g.scan_blocks, nb);
         hipLaunchKernelGGL(scan_add_kernel, dim3(nb), dim3(SCAN_THREADS), 0, s, g.point_offsets, g.scan_blocks, P);
@@ -102,10 +102,9 @@ int launch_scan(const GeometryState& g, int P, hipStream_t s) {
 // duplicate: thread i takes the i-th Gaussian in depth order and walks its tile rectangle
 // (y outer, x inner), emitting (tile id, Gaussian index)
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) duplicate_kernel(int P, const float* __restrict__ rec,
+__global__ void __launch_bounds__(256) duplicate_kernel(int P, const uint2* __restrict__ rects,
                                                         const uint32_t* __restrict__ perm,
-                                                        const uint32_t* __restrict__ offsets,
-                                                        const uint32_t* __restrict__ tiles_touched, uint32_t* keys,
+                                                        const uint32_t* __restrict__ offsets, uint32_t* keys,
                                                         uint32_t* vals, int gx, int gy, uint32_t r_cap,
                                                         int32_t* __restrict__ n_touched, uint2* __restrict__ ranges,
                                                         int ntiles, uint32_t* __restrict__ zero_ptr, size_t zero_words,
@@ -123,20 +122,14 @@ __global__ void __launch_bounds__(256) duplicate_kernel(int P, const float* __re
     if (i < P) n_touched[i] = 0;                         // (was a memset)
     uint32_t idx = 0, nt = 0, off = 0;
     int x0 = 0, y0 = 0, x1 = 0;
-    if (i < P) {
+    if (i < P) {                                         // everything in depth order and coalesced: no gather
         idx = perm[i];
-        nt = tiles_touched[idx];                         // 0: culled, its record was never written
+        const uint2 r = rects[i];                        // the rectangle preprocess computed (0 x 0: culled)
+        const int w = (int)(r.y & 0xFFFFu), h = (int)(r.y >> 16);
+        nt = (uint32_t)(w * h);
+        x0 = (int)(r.x & 0xFFFFu); y0 = (int)(r.x >> 16); x1 = x0 + w;
     }
-    if (nt) {
-        off = i == 0 ? 0u : offsets[i - 1];
-        const float4 r0 = reinterpret_cast<const float4*>(rec + (size_t)idx * REC_FLOATS)[0];
-        const float radius = rec[(size_t)idx * REC_FLOATS + R_RADIUS];
-        const float px = r0.x, py = r0.y;
-        // same expressions as preprocess (integer truncation of a float quotient)
-        x0 = min(gx, max(0, (int)((px - radius) / (float)TILE)));
-        y0 = min(gy, max(0, (int)((py - radius) / (float)TILE)));
-        x1 = min(gx, max(0, (int)(((px + radius) + (float)(TILE - 1)) / (float)TILE)));
-    }
+    if (nt) off = i == 0 ? 0u : offsets[i - 1];
     // Load-balanced emission.  The 64 Gaussians of the wave own the consecutive output slots [S, E); the wave walks
     // that range 64 slots at a time (aligned, so every store is one coalesced 256-byte line) and each lane finds the
     // owner of its slot: owners mark their first slot in LDS, an inclusive max-scan spreads the mark to the right.
@@ -186,8 +179,8 @@ int launch_duplicate(const mgs_camera& cam, int P, const GeometryState& g, const
     uint32_t* zero_ptr = nullptr;
     size_t zero_words = 0;
     if (sort_n > 0) radix_zero_region(b.sort_temp, sort_n, sort_bits, &zero_ptr, &zero_words);
-    hipLaunchKernelGGL(duplicate_kernel, dim3((n + 255) / 256), dim3(256), 0, s, P, g.rec, g.perm, g.point_offsets,
-                       g.tiles_touched, b.keys_a, b.vals_a, tiles_x(cam.image_width), tiles_y(cam.image_height),
+    hipLaunchKernelGGL(duplicate_kernel, dim3((n + 255) / 256), dim3(256), 0, s, P, g.rect_sorted, g.perm, g.point_offsets,
+                       b.keys_a, b.vals_a, tiles_x(cam.image_width), tiles_y(cam.image_height),
                        (uint32_t)(r_cap > 0xFFFFFFFFull ? 0xFFFFFFFFull : r_cap), n_touched, img.ranges, ntiles, zero_ptr,
                        zero_words, count, overflow);
     MGS_HIP(hipGetLastError());
@@ -201,7 +194,9 @@ size_t sort_temp_bytes(uint64_t n, int bits) { return radix_temp_bytes(n, bits);
 
 int launch_depth_sort(const GeometryState& g, int P, hipStream_t s) {
     // the scratch was cleared by preprocess_forward_kernel
-    return radix_sort_pairs(g.depth_key, g.iota, g.depth_alt, g.iota_alt, (uint64_t)P, 32, g.sort_temp, s, nullptr, true);
+    // (the last pass also lays the tile rectangles out in depth order for the scan and duplicate)
+    return radix_sort_pairs(g.depth_key, g.iota, g.depth_alt, g.iota_alt, (uint64_t)P, 32, g.sort_temp, s, nullptr, true,
+                            g.rect, g.rect_sorted);
 }
 
 int launch_sort(const BinningState& b, uint64_t R, int bits, hipStream_t s, const uint32_t* n_dev) {

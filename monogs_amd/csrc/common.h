@@ -114,6 +114,9 @@ struct GeometryState {
     uint32_t* point_offsets;  // [P] inclusive scan of tiles_touched[perm[i]]
     uint32_t* scan_blocks;    // [scan_nblocks(P) + 64]
     uint8_t* clamped;         // [P][4] SH colour clamp flags
+    uint2* rect;              // [P] tile rectangle {x0 | y0 << 16, w | h << 16} (w = h = 0: culled), by Gaussian index
+    uint2* rect_sorted;       // [P] the same in depth order: written by the last pass of the depth sort, so that the
+                              //     scan and duplicate read it coalesced instead of gathering through perm[]
     void* sort_temp;          // depth sort scratch
     size_t sort_temp_bytes;
     char* end;                // one past the last carved byte
@@ -184,7 +187,8 @@ bool radix_result_in_b(int bits);
 const uint32_t* radix_error_flag(void* temp, uint64_t n, int bits);
 void radix_zero_region(void* temp, uint64_t n, int bits, uint32_t** ptr, size_t* words);   // what must be 0 before a sort
 int radix_sort_pairs(uint32_t* ka, uint32_t* va, uint32_t* kb, uint32_t* vb, uint64_t n, int bits, void* temp,
-                     hipStream_t s, const uint32_t* n_dev = nullptr, bool temp_zeroed = false);
+                     hipStream_t s, const uint32_t* n_dev = nullptr, bool temp_zeroed = false,
+                     const uint2* aux_in = nullptr, uint2* aux_out = nullptr);   // last pass also writes aux_out[i] = aux_in[value i]
 int launch_depth_sort(const GeometryState& g, int P, hipStream_t s);
 int launch_sort(const BinningState& b, uint64_t R, int bits, hipStream_t s, const uint32_t* n_dev = nullptr);
 int launch_ranges(const BinningState& b, uint64_t R, const ImageState& img, int ntiles, hipStream_t s,

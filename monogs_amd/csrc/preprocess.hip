@@ -145,6 +145,7 @@ struct PreArgs {
     uint32_t* depth_key;
     uint32_t* iota;
     uint8_t* clamped;
+    uint2* rect;
     int32_t* radii;
     float tanfovx, tanfovy, focal_x, focal_y, mod;
     int P, W, H, gx, gy, deg, M;
@@ -158,6 +159,7 @@ __global__ void __launch_bounds__(256) preprocess_forward_kernel(PreArgs a) {
     if (idx >= a.P) return;
     a.radii[idx] = 0;
     a.tiles_touched[idx] = 0;
+    a.rect[idx] = make_uint2(0u, 0u);
     a.depth_key[idx] = 0xFFFFFFFFu;       // culled Gaussians sort behind every visible one
     a.iota[idx] = (uint32_t)idx;
 
@@ -245,6 +247,7 @@ __global__ void __launch_bounds__(256) preprocess_forward_kernel(PreArgs a) {
     rec[3] = make_float4(na, nb, nc, radius);
     a.radii[idx] = (int)radius;
     a.tiles_touched[idx] = (uint32_t)ntile;
+    a.rect[idx] = make_uint2((uint32_t)x0 | ((uint32_t)y0 << 16), (uint32_t)(x1 - x0) | ((uint32_t)(y1 - y0) << 16));
     a.depth_key[idx] = __float_as_uint(pv[2]);   // > 0.2, so the bit pattern orders like the value
 }
 
@@ -257,7 +260,7 @@ int launch_preprocess_forward(const mgs_camera& cam, int P, const float* means3D
     a.scales = scales; a.rotations = rotations; a.cov3D = cov3D_precomp;
     a.V = cam.viewmatrix; a.PM = cam.projmatrix; a.campos = cam.campos;
     a.rec = g.rec; a.tiles_touched = g.tiles_touched; a.depth_key = g.depth_key; a.iota = g.iota;
-    a.clamped = g.clamped; a.radii = radii;
+    a.clamped = g.clamped; a.rect = g.rect; a.radii = radii;
     a.tanfovx = cam.tanfovx; a.tanfovy = cam.tanfovy;
     a.focal_x = (float)cam.image_width / (2.0f * cam.tanfovx);
     a.focal_y = (float)cam.image_height / (2.0f * cam.tanfovy);

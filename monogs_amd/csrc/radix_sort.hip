@@ -190,6 +190,8 @@ struct RsPassArgs {
     uint64_t* status;         // [tiles][256]
     uint32_t* ticket;
     uint32_t* error;
+    const uint2* aux_in;      // optional (last pass): aux_out[final position] = aux_in[value]
+    uint2* aux_out;
     const uint32_t* scanned;  // SCANNED path: [256][tiles] exclusive scan (digit-major) of the per-tile digit counts
     uint32_t tiles;
 };
@@ -356,8 +358,10 @@ __global__ void __launch_bounds__(RS_THREADS) rs_pass_kernel(RsPassArgs a) {
         if (p < tile_n) {
             const uint32_t k = skeys[p];
             const int64_t g = gbase[(k >> a.shift) & 0xFFu] + (int64_t)p;
+            const uint32_t v = svals[p];
             a.kout[g] = k;
-            a.vout[g] = svals[p];
+            a.vout[g] = v;
+            if (a.aux_out) a.aux_out[g] = a.aux_in[v];
         }
     }
 }
@@ -377,17 +381,18 @@ const uint32_t* radix_error_flag(void* temp, uint64_t n, int bits) { return rs_c
 void radix_zero_region(void* temp, uint64_t n, int bits, uint32_t** ptr, size_t* words) {
     const RsTemp t = rs_carve(temp, n ? n : 1, bits);
     *ptr = t.hist;
-    *words = t.zero_bytes / 4;
+    // the SCANNED path never reads the status words (it reuses their storage for counts it fully overwrites)
+    *words = rs_scanned(n) ? (size_t)((char*)t.status - (char*)t.hist) / 4 : t.zero_bytes / 4;
 }
 
 int radix_sort_pairs(uint32_t* ka, uint32_t* va, uint32_t* kb, uint32_t* vb, uint64_t n, int bits, void* temp,
-                     hipStream_t s, const uint32_t* n_dev, bool temp_zeroed) {
+                     hipStream_t s, const uint32_t* n_dev, bool temp_zeroed, const uint2* aux_in, uint2* aux_out) {
     if (n == 0) return 0;
     if (n >= (1ull << 32)) { set_error("radix sort: more than 2^32-1 pairs"); return 1; }
     const int npasses = rs_passes(bits);
     if (npasses > RS_MAX_PASSES) { set_error("radix sort: more than 32 key bits"); return 1; }
     const RsTemp t = rs_carve(temp, n, bits);
-    if (!temp_zeroed) MGS_HIP(zero_fill(t.hist, t.zero_bytes, s));
+    if (!temp_zeroed) MGS_HIP(zero_fill(t.hist, rs_scanned(n) ? (size_t)((char*)t.status - (char*)t.hist) : t.zero_bytes, s));
     const uint32_t tiles = rs_tiles(n);
     const uint32_t hist_blocks = min(tiles, 1024u);
     const bool scanned = rs_scanned(n);
@@ -405,6 +410,8 @@ int radix_sort_pairs(uint32_t* ka, uint32_t* va, uint32_t* kb, uint32_t* vb, uin
         a.ticket = tiles <= 256u ? nullptr : t.tickets + p;
         a.error = t.error;
         a.scanned = counts; a.tiles = tiles;
+        const bool last = p == npasses - 1;
+        a.aux_in = last ? aux_in : nullptr; a.aux_out = last ? aux_out : nullptr;
         if (scanned) {
             // t.hist[p] receives the digit bases, t.base[p] the row totals, t.tickets[p] counts finished workgroups
             hipLaunchKernelGGL(rs_tile_hist_kernel<RS_ITEMS>, dim3(tiles), dim3(RS_THREADS), 0, s, kin, (uint32_t)n, n_dev,

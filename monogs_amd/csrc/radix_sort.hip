@@ -138,19 +138,14 @@ __global__ void __launch_bounds__(RS_THREADS) rs_tile_hist_kernel(const uint32_t
     counts[(size_t)t * tiles + tile] = (wh[0][t] + wh[1][t]) + (wh[2][t] + wh[3][t]);     // dead tiles write zeros
 }
 
-// ---- SCANNED path, step 2: counts[digit][tile] -> exclusive scan along the tiles of each digit, plus the global base
-// of every digit.  One wave per digit: lane l sums a contiguous segment of the row, ONE 64-lane scan joins the
-// segments (a scan per 64-element chunk went through ds_bpermute 7 times per chunk: 8.7 us for 125 k counts).  The
-// row totals go to `totals`; the last workgroup to finish (atomic ticket, no waiting) scans the 256 totals into
-// `base`, which the scatter kernel adds.  That replaces the separate all-pass histogram kernel.
+// ---- SCANNED path, step 2: counts[digit][tile] -> exclusive scan along the tiles of each digit; the row total goes to
+// totals[digit] (the scatter kernel turns the 256 totals into digit bases itself, as the one-sweep path does with
+// the global histogram).  One wave per digit, 64 tiles per step, DPP scan (the first version used __shfl_up, i.e.
+// ds_bpermute, seven times per step: 8.7 us for 125 k counts).
 __global__ void __launch_bounds__(RS_THREADS) rs_row_scan_kernel(uint32_t* __restrict__ counts, uint32_t tiles,
-                                                                 uint32_t* __restrict__ totals /* [256] */,
-                                                                 uint32_t* __restrict__ base /* [256] */,
-                                                                 uint32_t* __restrict__ ticket) {
-    __shared__ uint32_t s_last;
-    __shared__ uint32_t s_w[RS_WAVES];
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    const uint32_t d = blockIdx.x * RS_WAVES + wv;                          // 0..255
+                                                                 uint32_t* __restrict__ totals /* [256] */) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t d = blockIdx.x * RS_WAVES + (threadIdx.x >> 6);          // 0..255
     uint32_t* row = counts + (size_t)d * tiles;
     uint32_t carry = 0;                                                     // wave-uniform
     uint32_t next = lane < tiles ? row[lane] : 0u;                          // one chunk in flight ahead of the scan
@@ -162,20 +157,7 @@ __global__ void __launch_bounds__(RS_THREADS) rs_row_scan_kernel(uint32_t* __res
         if (i < tiles) row[i] = carry + incl - v;
         carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     }
-    if (lane == 0) __hip_atomic_store(totals + d, carry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __threadfence();
-    __syncthreads();
-    if (t == 0) s_last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
-    __syncthreads();
-    if (!s_last) return;
-    // last workgroup: every row total has been published (release above, agent-scope loads here)
-    const uint32_t tot = __hip_atomic_load(totals + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const uint32_t ti = wave_incl_scan_dpp(tot);
-    if (lane == 63) s_w[wv] = ti;
-    __syncthreads();
-    uint32_t add = 0;
-    for (int w = 0; w < wv; ++w) add += s_w[w];
-    base[t] = add + ti - tot;
+    if (lane == 0) totals[d] = carry;
 }
 
 struct RsPassArgs {
@@ -186,7 +168,7 @@ struct RsPassArgs {
     uint32_t n;               // number of pairs (capacity when n_dev is set)
     const uint32_t* n_dev;    // optional: live count on the device (<= n after clamping)
     int shift;
-    const uint32_t* hist;     // [256] global count of each digit for this pass (SCANNED path: global BASE of each digit)
+    const uint32_t* hist;     // [256] global count of each digit for this pass
     uint64_t* status;         // [tiles][256]
     uint32_t* ticket;
     uint32_t* error;
@@ -274,22 +256,21 @@ __global__ void __launch_bounds__(RS_THREADS) rs_pass_kernel(RsPassArgs a) {
     for (int w = 0; w < wv; ++w) wadd += wsum[w];
     const uint32_t dbase = wadd + incl - total;
     digit_base[t] = dbase;
+    // exclusive global base of digit t = scan of this pass's 256 digit totals (global histogram on the one-sweep path,
+    // row totals of rs_row_scan_kernel on the SCANNED path): cheaper here than a separate launch
+    const uint32_t hcount = a.hist[t];
+    const uint32_t hincl = wave_incl_scan_dpp(hcount);
+    __syncthreads();                     // wsum is reused
+    if (lane == 63) wsum[wv] = hincl;
+    __syncthreads();
+    uint32_t hadd = 0;
+    for (int w = 0; w < wv; ++w) hadd += wsum[w];
+    const uint32_t gdigit_base = hadd + hincl - hcount;
     if (SCANNED) {
-        // absolute position of this tile's run of digit t, straight from the scanned table
-        gbase[t] = (int64_t)a.hist[t] + (int64_t)a.scanned[(size_t)t * a.tiles + tile] - (int64_t)dbase;
+        // position of this tile's run of digit t inside the digit: straight from the scanned table
+        gbase[t] = (int64_t)gdigit_base + (int64_t)a.scanned[(size_t)t * a.tiles + tile] - (int64_t)dbase;
         __syncthreads();
     } else {
-        // exclusive global base of digit t = scan of this pass's global histogram (256 values: cheaper here
-        // than a separate launch between the histogram and the first pass)
-        const uint32_t hcount = a.hist[t];
-        const uint32_t hincl = wave_incl_scan_dpp(hcount);
-        __syncthreads();                     // wsum is reused
-        if (lane == 63) wsum[wv] = hincl;
-        __syncthreads();
-        uint32_t hadd = 0;
-        for (int w = 0; w < wv; ++w) hadd += wsum[w];
-        const uint32_t gdigit_base = hadd + hincl - hcount;
-
         // ---- publish, look back, publish (one digit per thread)
         uint64_t* my = a.status + (size_t)tile * RS_RADIX + t;
         uint64_t prefix = 0;
@@ -413,11 +394,11 @@ int radix_sort_pairs(uint32_t* ka, uint32_t* va, uint32_t* kb, uint32_t* vb, uin
         const bool last = p == npasses - 1;
         a.aux_in = last ? aux_in : nullptr; a.aux_out = last ? aux_out : nullptr;
         if (scanned) {
-            // t.hist[p] receives the digit bases, t.base[p] the row totals, t.tickets[p] counts finished workgroups
+            // t.hist[p] receives the 256 digit totals
             hipLaunchKernelGGL(rs_tile_hist_kernel<RS_ITEMS>, dim3(tiles), dim3(RS_THREADS), 0, s, kin, (uint32_t)n, n_dev,
                                a.shift, tiles, counts);
             hipLaunchKernelGGL(rs_row_scan_kernel, dim3(RS_RADIX / RS_WAVES), dim3(RS_THREADS), 0, s, counts, tiles,
-                               t.base + p * RS_RADIX, t.hist + p * RS_RADIX, t.tickets + p);
+                               t.hist + p * RS_RADIX);
             hipLaunchKernelGGL((rs_pass_kernel<RS_ITEMS, true>), dim3(tiles), dim3(RS_THREADS), 0, s, a);
         } else if (rs_items(n) == RS_ITEMS_SMALL)
             hipLaunchKernelGGL((rs_pass_kernel<RS_ITEMS_SMALL, false>), dim3(tiles), dim3(RS_THREADS), 0, s, a);

@@ -199,6 +199,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                               opac_, sc_ if sc_ is not None else dummy, rot_ if rot_ is not None else dummy,
                               cov_ if cov_ is not None else dummy, radii, geom, binning, img)
         ctx.mark_non_differentiable(radii, n_touched)
+        ctx.set_materialize_grads(False)     # unused output gradients arrive as None instead of three zero-fill kernels
         return color, radii, depth, opacity, n_touched
 
     @staticmethod

@@ -27,6 +27,7 @@ import torch
 from . import camera as cam
 from .knn import distCUDA2
 from .renderer import render
+from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
 from . import fused_losses, slam_losses
 from .gaussian_optim import GaussianAdam, activate
 from .pose_optim import PoseAdam
@@ -185,6 +186,7 @@ class TrackingGraph:
         self.flags = [torch.zeros(1, pin_memory=True) for _ in range(2)]
         self.events = [torch.cuda.Event() for _ in range(2)]
         self.graph = None
+        self.zero2d = torch.zeros_like(self.map[0])
         self._load(proto)
         keep = (self.svp.R.clone(), self.svp.T.clone(), self.svp.exposure_a.data.clone(), self.svp.exposure_b.data.clone())
         # eager warm-up on a side stream (also records the capacity hint for this map size), then capture
@@ -194,15 +196,33 @@ class TrackingGraph:
             self._iteration()
         torch.cuda.current_stream().wait_stream(s)
         self.opt.zero_grad()
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self._iteration()
+        # two executable graphs of the same iteration, replayed alternately: launching a graph that is still running
+        # waits for it, a second instance lets replay n+1 queue behind replay n (the ~30 us launch gap disappears)
+        self.graphs = []
+        for _ in range(2):
+            self.opt.zero_grad()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._iteration()
+            self.graphs.append(g)
+        self.graph = self.graphs[0]
         with torch.no_grad():          # undo the warm-up step
             self.svp.R.copy_(keep[0]); self.svp.T.copy_(keep[1])
             self.svp.exposure_a.data.copy_(keep[2]); self.svp.exposure_b.data.copy_(keep[3])
 
     def _iteration(self):
-        pkg = render(self.svp, self.intr, *self.map, self.bg)
+        # render() without what tracking never reads: no screen-space gradient holder, no visibility filter
+        xyz, rot, sca3, opa, col = self.map
+        view, full, campos = cam.fused_camera_matrices(self.svp.R, self.svp.T, self.intr.projection_matrix)
+        rs = GaussianRasterizationSettings(
+            image_height=int(self.intr.height), image_width=int(self.intr.width),
+            tanfovx=math.tan(self.intr.FoVx * 0.5), tanfovy=math.tan(self.intr.FoVy * 0.5), bg=self.bg, scale_modifier=1.0,
+            viewmatrix=view, projmatrix=full, projmatrix_raw=self.intr.projection_matrix, sh_degree=0, campos=campos,
+            prefiltered=False, debug=False)
+        color, _, depth, opacity, _ = GaussianRasterizer(rs)(
+            means3D=xyz, means2D=self.zero2d, opacities=opa, colors_precomp=col, scales=sca3, rotations=rot,
+            theta=self.svp.cam_rot_delta, rho=self.svp.cam_trans_delta)
+        pkg = {"render": color, "depth": depth, "opacity": opacity}
         self.opt.zero_grad()
         loss = fused_losses.get_loss_tracking(pkg["render"], pkg["depth"], pkg["opacity"], self.svp)
         loss.backward()      # (an explicit gradient= tensor costs ~140 ms on its first call and saves one 4 us fill)
@@ -217,14 +237,14 @@ class TrackingGraph:
         s.cam_rot_delta.data.zero_(); s.cam_trans_delta.data.zero_()
         self.opt.reset()
 
-    def track(self, vp: Viewpoint, max_iters: int, lookahead: int = 0) -> int:
+    def track(self, vp: Viewpoint, max_iters: int, lookahead: int = 1) -> int:
         """lookahead = 0: read the convergence flag after every replay (one 4-byte read-back per iteration).
         lookahead = 1: launch replay n before reading the flag of replay n-1 (hides the read-back; relies on the sticky
         flag making the surplus replay a no-op)."""
         self._load(vp)
         n_done = max_iters
         for n in range(max_iters):
-            self.graph.replay()
+            self.graphs[n & 1].replay()
             self.flags[n & 1].copy_(self.opt.out[:1], non_blocking=True)
             self.events[n & 1].record()
             m = n - lookahead
@@ -244,6 +264,7 @@ class TrackingGraph:
     def close(self):
         self._r.clear_graph_flags()
         self.graph = None
+        self.graphs = []
 
 
 def make_sequence(n_frames: int, intrinsics="fr3_office", n_gaussians=60000, seed=11, device="cuda:0"):
@@ -275,7 +296,7 @@ def make_sequence(n_frames: int, intrinsics="fr3_office", n_gaussians=60000, see
 def run_slam(n_frames=12, intrinsics="fr3_office", tracking_itr_num=100, mapping_itr_num=150, window_size=8,
              kf_interval=4, init_itr_num=300, n_gaussians=60000, device="cuda:0", log=None,
              init_downsample=8, kf_downsample=16, point_size=1.0, fused_losses_on=True, fused_pose_on=True, graph_tracking=False, graph_mapping=False,
-             track_lookahead=0):
+             track_lookahead=1):
     """Returns a dict with tracking / mapping FPS, iterations and the trajectory error."""
     frames, intr = make_sequence(n_frames, intrinsics, n_gaussians, device=device)
     L = fused_losses if fused_losses_on else slam_losses

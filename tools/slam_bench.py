@@ -29,7 +29,7 @@ if __name__ == "__main__":
     ap.add_argument("--eager-mapping", action="store_true", help="with --graph: capture tracking only")
     ap.add_argument("--torch-pose", action="store_true", help="torch.optim.Adam + Python retraction instead of mgs_pose_step")
     ap.add_argument("--torch-losses", action="store_true", help="use the plain PyTorch losses instead of the fused HIP ones")
-    ap.add_argument("--lookahead", type=int, default=0, choices=[0, 1],
+    ap.add_argument("--lookahead", type=int, default=1, choices=[0, 1],
                     help="with --graph: read the convergence flag of tracking iteration n-1 while n runs")
     a = ap.parse_args()
     from monogs_amd.slam_harness import run_slam

@@ -192,6 +192,17 @@ def test_c5_full_size_properties(native_lib, monkeypatch):
     monkeypatch.delenv("MGS_RADIX_SCANNED")
     assert torch.equal(t["point_list"], t3["point_list"]) and torch.equal(t["ranges"], t3["ranges"])
     assert torch.equal(t["color"], t3["color"])
+    # capacity mode (device-side instance count; what bench.py times) renders the same image as the exact path
+    from monogs_amd import rasterizer as _r
+    _r.set_sync_free(True)
+    try:
+        with torch.no_grad():
+            cap = GaussianRasterizer(st)(means3D=dev(sc.means3D), means2D=torch.zeros_like(dev(sc.means3D)),
+                                         opacities=dev(sc.opacities), **args)
+        assert not _r.check_overflow()
+    finally:
+        _r.set_sync_free(False)
+    assert torch.equal(cap[0], t["color"]) and torch.equal(cap[4], t["n_touched"])
     # backward: linear in the upstream gradient
     def grads(scale):
         m = dev(sc.means3D).clone().requires_grad_(True)

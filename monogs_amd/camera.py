@@ -40,6 +40,7 @@ def fused_camera_matrices(R: torch.Tensor, t: torch.Tensor, projmatrix_raw: torc
     (``mgs_camera_setup``).  Same values as ``world2view(R, t).T``, ``viewmatrix @ projmatrix_raw`` and
     ``viewmatrix.inverse()[3, :3]``; no autograd (the rasteriser gives the camera tensors no gradient)."""
     from . import _lib
+    from .rasterizer import _stream, _device_guard
     lib = _lib.load()
     f = lambda x: x.detach().to(torch.float32).contiguous()  # noqa: E731
     R, t, Pm = f(R), f(t), f(projmatrix_raw)
@@ -47,9 +48,9 @@ def fused_camera_matrices(R: torch.Tensor, t: torch.Tensor, projmatrix_raw: torc
     view = torch.empty(4, 4, dtype=torch.float32, device=dev)
     full = torch.empty(4, 4, dtype=torch.float32, device=dev)
     campos = torch.empty(3, dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _device_guard(dev):
         _lib.check(lib.mgs_camera_setup(R.data_ptr(), t.data_ptr(), Pm.data_ptr(), view.data_ptr(), full.data_ptr(),
-                                        campos.data_ptr(), torch.cuda.current_stream().cuda_stream), "mgs_camera_setup")
+                                        campos.data_ptr(), _stream()), "mgs_camera_setup")
     return view, full, campos
 
 

@@ -8,7 +8,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from .rasterizer import _camera, _f32, _ptr, _stream
+from .rasterizer import _camera, _f32, _ptr, _stream, _device_guard
 
 
 def _au(v, a=256):
@@ -26,7 +26,7 @@ def forward_tables(rs, means3D, opacities, colors_precomp=None, shs=None, scales
     means3D, opacities = c(means3D, "means3D"), c(opacities, "opacities")
     colors_precomp, shs, scales = c(colors_precomp, "colors"), c(shs, "shs"), c(scales, "scales")
     rotations, cov3D_precomp = c(rotations, "rotations"), c(cov3D_precomp, "cov3D")
-    with torch.cuda.device(dev):
+    with _device_guard(dev):
         keep = []
         cam = _camera(rs, 0 if shs is None else shs.shape[1], keep)
         u8 = dict(dtype=torch.uint8, device=dev)

@@ -12,7 +12,7 @@ from __future__ import annotations
 import torch
 
 from . import _lib
-from .rasterizer import _f32, _stream
+from .rasterizer import _f32, _stream, _device_guard
 
 
 _DAB = 10     # MGS_LOSS_SCRATCH_DAB (include/monogs_raster.h)
@@ -39,7 +39,7 @@ class _FusedLoss(torch.autograd.Function):
         a = _f32(exp_a.detach(), "exposure_a") if exp_a is not None else None
         b = _f32(exp_b.detach(), "exposure_b") if exp_b is not None else None
         p = lambda t: None if t is None else t.data_ptr()  # noqa: E731
-        with torch.cuda.device(dev):
+        with _device_guard(dev):
             scratch = torch.empty(lib.mgs_loss_scratch_bytes() // 4, dtype=torch.float32, device=dev)
             loss = torch.empty((), dtype=torch.float32, device=dev)
             _lib.check(lib.mgs_loss_forward(W, H, int(tracking), int(init), float(lam), p(render), p(depth), p(opac),
@@ -60,7 +60,7 @@ class _FusedLoss(torch.autograd.Function):
         W, H, tracking, init, lam = ctx.cfg
         dev = render.device
         p = lambda t, ok=True: t.data_ptr() if ok else None  # noqa: E731
-        with torch.cuda.device(dev):
+        with _device_guard(dev):
             go = _f32(grad_out.reshape(1), "grad_output")
             d_render = torch.empty_like(render)
             d_depth = torch.empty_like(depth)

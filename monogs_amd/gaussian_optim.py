@@ -13,7 +13,7 @@ from typing import Sequence
 import torch
 
 from . import _lib
-from .rasterizer import _stream
+from .rasterizer import _stream, _device_guard
 
 
 class GaussianAdam:
@@ -42,7 +42,7 @@ class GaussianAdam:
         tab = lambda ts: vp(*[None if t is None else t.data_ptr() for t in ts])  # noqa: E731
         numel = (C.c_uint64 * n)(*[p.numel() for p in self.params])
         lr = (C.c_float * n)(*self.lrs)
-        with torch.cuda.device(self.params[0].device):
+        with _device_guard(self.params[0].device):
             _lib.check(lib.mgs_adam_step(n, tab(self.params), tab(grads), tab(self.exp_avg), tab(self.exp_avg_sq), numel,
                                          lr, self.betas[0], self.betas[1], self.eps, 0, self.t_dev.data_ptr(), _stream()),
                        "mgs_adam_step")
@@ -56,7 +56,7 @@ def add_densification_stats(viewspace_grad: torch.Tensor, radii: torch.Tensor, x
     P = radii.shape[0]
     g = viewspace_grad.contiguous()
     p = lambda t: None if t is None else t.data_ptr()  # noqa: E731
-    with torch.cuda.device(radii.device):
+    with _device_guard(radii.device):
         _lib.check(lib.mgs_densify_stats(P, g.data_ptr(), radii.contiguous().data_ptr(), p(xyz_gradient_accum), p(denom),
                                          p(max_radii_2d), _stream()), "mgs_densify_stats")
 
@@ -71,7 +71,7 @@ class _Activate(torch.autograd.Function):
         rot = torch.empty(P, 4, device=dev)
         scales3 = torch.empty(P, 3, device=dev)
         opac = torch.empty(P, 1, device=dev)
-        with torch.cuda.device(dev):
+        with _device_guard(dev):
             _lib.check(lib.mgs_activate_forward(P, sd, rot_raw.data_ptr(), scale_raw.data_ptr(), opacity_raw.data_ptr(),
                                                 rot.data_ptr(), scales3.data_ptr(), opac.data_ptr(), _stream()),
                        "mgs_activate_forward")
@@ -90,7 +90,7 @@ class _Activate(torch.autograd.Function):
         d_opac = torch.empty(P, 1, device=dev) if need[2] else None
         p = lambda t: None if t is None else t.contiguous().data_ptr()  # noqa: E731
         keep = [t.contiguous() if t is not None else None for t in (g_rot, g_scales3, g_opac)]
-        with torch.cuda.device(dev):
+        with _device_guard(dev):
             _lib.check(lib.mgs_activate_backward(P, ctx.sd, rot_raw.data_ptr(), scales3.data_ptr(), opac.data_ptr(),
                                                  p(keep[0]), p(keep[1]), p(keep[2]), p(d_rot), p(d_scale), p(d_opac),
                                                  _stream()), "mgs_activate_backward")

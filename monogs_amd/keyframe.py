@@ -27,7 +27,7 @@ import torch
 
 from . import _lib
 from .knn import distCUDA2
-from .rasterizer import _stream
+from .rasterizer import _stream, _device_guard
 
 
 def densification_mask(gt_depth: torch.Tensor, render_depth: Optional[torch.Tensor], render_opacity: Optional[torch.Tensor],
@@ -80,7 +80,7 @@ def create_viewpoint_pcd(viewpoint, cam_intrinsics, render_depth=None, render_op
     p = lambda t: None if t is None else t.data_ptr()  # noqa: E731
     ea = None if init else viewpoint.exposure_a.detach().to(torch.float32).contiguous()
     eb = None if init else viewpoint.exposure_b.detach().to(torch.float32).contiguous()
-    with torch.cuda.device(dev):
+    with _device_guard(dev):
         _lib.check(lib.mgs_backproject(N, W, H, p(sel), p(rgb), p(depth), p(seg32), p(ea), p(eb), fx, fy, cx, cy, p(R), p(T),
                                        p(pts), p(feat), p(ids), _stream()), "mgs_backproject")
     if N > 0:

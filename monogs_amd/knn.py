@@ -8,6 +8,7 @@ from __future__ import annotations
 import torch
 
 from . import _lib
+from .rasterizer import _stream, _device_guard
 
 
 def distCUDA2(points: torch.Tensor) -> torch.Tensor:
@@ -19,8 +20,8 @@ def distCUDA2(points: torch.Tensor) -> torch.Tensor:
         raise RuntimeError(f"distCUDA2 expects [P,3], got {tuple(pts.shape)}")
     P = pts.shape[0]
     out = torch.empty(P, dtype=torch.float32, device=pts.device)
-    with torch.cuda.device(pts.device):
+    with _device_guard(pts.device):
         scratch = torch.empty(lib.mgs_knn_scratch_bytes(P), dtype=torch.uint8, device=pts.device)
         _lib.check(lib.mgs_dist2_knn(P, pts.data_ptr(), out.data_ptr(), scratch.data_ptr(),
-                                     torch.cuda.current_stream().cuda_stream), "mgs_dist2_knn")
+                                     _stream()), "mgs_dist2_knn")
     return out

@@ -10,7 +10,7 @@ from __future__ import annotations
 import torch
 
 from . import _lib
-from .rasterizer import _stream
+from .rasterizer import _stream, _device_guard
 
 
 class PoseAdam:
@@ -47,7 +47,7 @@ class PoseAdam:
         if R.data_ptr() != vp.R.data_ptr() or T.data_ptr() != vp.T.data_ptr():
             vp.R, vp.T = R, T
         g = lambda p: None if p.grad is None else p.grad.contiguous().data_ptr()  # noqa: E731
-        with torch.cuda.device(R.device):
+        with _device_guard(R.device):
             _lib.check(lib.mgs_pose_step(R.data_ptr(), T.data_ptr(), vp.cam_rot_delta.data_ptr(),
                                          vp.cam_trans_delta.data_ptr(), vp.exposure_a.data_ptr(),
                                          vp.exposure_b.data_ptr(), g(vp.cam_rot_delta), g(vp.cam_trans_delta),

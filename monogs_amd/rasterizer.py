@@ -112,7 +112,38 @@ def _camera(rs: GaussianRasterizationSettings, sh_coeffs: int, keep: list) -> _l
     return cam
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
+class _device_guard:
+    """``with _device_guard(dev)`` for the common case.  The stock context manager spends ~45 us per use in this
+    torch build (``_get_device_index`` consults the environment on entry and exit); five uses per render + loss +
+    backward were ~0.2 ms of host time per iteration (tools/host_overhead.py).  Here nothing happens unless ``dev``
+    is not the current device."""
+    __slots__ = ("idx", "prev")
+
+    def __init__(self, dev):
+        idx = getattr(dev, "index", dev)
+        self.idx = torch._C._cuda_getDevice() if idx is None else int(idx)
+
+    def __enter__(self):
+        self.prev = torch._C._cuda_getDevice()
+        if self.prev != self.idx:
+            torch._C._cuda_setDevice(self.idx)
+        return self
+
+    def __exit__(self, *exc):
+        if self.prev != self.idx:
+            torch._C._cuda_setDevice(self.prev)
+        return False
+
+
 def _stream():
+    """Raw handle of the caller's current stream.  torch.cuda.current_stream() costs ~40 us per call in this torch
+    build (environment lookups inside _get_device_index) -- four calls per render + backward; the C-level accessor
+    is ~100x cheaper (tools/host_overhead.py)."""
+    if _raw_stream is not None:
+        return _raw_stream(torch._C._cuda_getDevice())
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -135,7 +166,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         M = 0 if sh_ is None else int(sh_.shape[1])
         H, W = int(rs.image_height), int(rs.image_width)
 
-        with torch.cuda.device(dev):
+        with _device_guard(dev):
             keep = []
             cam = _camera(rs, M, keep)
             timing = _lib.MgsTiming() if _timing_sink is not None else None
@@ -214,7 +245,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         H, W = int(rs.image_height), int(rs.image_width)
         need = ctx.needs_input_grad   # means3D, means2D, sh, colors, opacities, scales, rotations, cov3D, theta, rho
 
-        with torch.cuda.device(dev):
+        with _device_guard(dev):
             keep = []
             cam = _camera(rs, ctx.sh_coeffs, keep)
             f32 = dict(dtype=torch.float32, device=dev)
@@ -272,7 +303,7 @@ class GaussianRasterizer(nn.Module):
             pos = _f32(positions, "positions")
             P = pos.shape[0]
             vis = torch.zeros(P, dtype=torch.uint8, device=pos.device)
-            with torch.cuda.device(pos.device):
+            with _device_guard(pos.device):
                 vm = _f32(rs.viewmatrix, "viewmatrix")
                 pm = _f32(rs.projmatrix, "projmatrix")
                 _lib.check(lib.mgs_mark_visible(P, pos.data_ptr(), vm.data_ptr(), pm.data_ptr(), vis.data_ptr(),

@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Where does the HOST time of an eager render + backward go?  (cProfile over a few hundred small iterations)"""
+import cProfile
+import os
+import pstats
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from monogs_amd.slam_harness import Intrinsics, Viewpoint
+from monogs_amd.renderer import render
+from monogs_amd.synthetic import make_scene
+from monogs_amd import fused_losses
+
+dev = "cuda:0"
+sc = make_scene(39000, "fr3_office", seed=11, near_fraction=0.0, device=dev)
+intr = Intrinsics(sc.intr, dev)
+vp = Viewpoint(0, torch.rand(3, intr.height, intr.width, device=dev), torch.ones(intr.height, intr.width, device=dev), dev)
+vp.update_RT(sc.R.to(dev).contiguous(), sc.t.to(dev).contiguous())
+P = [t.clone().requires_grad_(True) for t in (sc.means3D, sc.rotations, sc.scales, sc.opacities, sc.colors)]
+bg = torch.zeros(3, device=dev)
+
+
+def step():
+    pkg = render(vp, intr, *P, bg)
+    loss = fused_losses.get_loss_mapping(pkg["render"], pkg["depth"], vp)
+    loss.backward()
+    for p in P:
+        p.grad = None
+
+
+for _ in range(20):
+    step()
+torch.cuda.synchronize()
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+t0 = time.perf_counter()
+for _ in range(n):
+    step()
+torch.cuda.synchronize()
+print(f"eager exact-count: {(time.perf_counter() - t0) / n * 1e3:.3f} ms / iteration")
+pr = cProfile.Profile()
+pr.enable()
+for _ in range(n):
+    step()
+torch.cuda.synchronize()
+pr.disable()
+pstats.Stats(pr).sort_stats("tottime").print_stats(22)

@@ -73,7 +73,7 @@ class Viewpoint:
         return self.world_view_transform.inverse()[3, :3]
 
     def update_RT(self, R, t):
-        self.R, self.T = R.to(self.device), t.to(self.device)
+        self.R, self.T = R.to(self.device).contiguous(), t.to(self.device).contiguous()
 
     def retract(self, thr=1e-4) -> bool:
         """update_pose (/root/reference/utils/pose_utils.py:76-93) on device tensors."""
@@ -319,10 +319,11 @@ def run_slam(n_frames=12, intrinsics="fr3_office", tracking_itr_num=100, mapping
         kf_opt = torch.optim.Adam(pose_params) if pose_params else None
 
         def iteration():
-            loss = 0
+            loss = None
             for vp in window:
                 pkg = _render(vp, intr, gmap, bg)
-                loss = loss + get_loss_mapping(pkg["render"], pkg["depth"], vp, init=init)
+                term = get_loss_mapping(pkg["render"], pkg["depth"], vp, init=init)
+                loss = term if loss is None else loss + term
             loss.backward()
             with torch.no_grad():
                 gmap.optimizer.step()

@@ -265,7 +265,9 @@ int mgs_backward(const mgs_camera* cam, int32_t P, uint64_t R, const float* mean
     MGS_HIP(zero_fill2(grad_acc, (size_t)P * GRAD_FLOATS * sizeof(float), dL_dtau, 6 * sizeof(float), s));
     tm.mark();
     if (R > 0) {
-        if (int rc = launch_blend_backward(*cam, g, b, img, dL_dcolor, dL_ddepth, grad_acc, s)) return rc;
+        // colours / opacities take no gradient and do not feed the geometry (no SH): the lighter blend backward
+        const bool pose_only = !dL_dcolors && !dL_dopacity && !dL_dsh && !shs;
+        if (int rc = launch_blend_backward(*cam, g, b, img, dL_dcolor, dL_ddepth, grad_acc, pose_only, s)) return rc;
     }
     tm.mark();
     GeomBackwardArgs a;

@@ -250,6 +250,24 @@ __device__ __forceinline__ float reduce10(float a0, float a1, float a2, float a3
     return pos == 15 ? c0 : (pos == 0 ? c1 : c2);
 }
 
+// Pose-only variant (colours and opacities take no gradient -- tracking): six sums, slots {SX, SY, SXX, SXY, SYY, DDEPTH}
+//   lane 15: a0   lane 31: a2   lane 47: a1   lane 63: a3      (register c0)
+//   lane  0: a4   lane 32: a5                                  (register c1)
+__device__ __forceinline__ int reduce6_slot(int lane) {
+    const int row = lane >> 4, pos = lane & 15;
+    if (pos == 15) return row == 0 ? G_SX : row == 1 ? G_SXX : row == 2 ? G_SY : G_SXY;
+    if (pos == 0) return row == 0 ? G_SYY : row == 2 ? G_DDEPTH : -1;
+    return -1;
+}
+__device__ __forceinline__ float reduce6(float a0, float a1, float a2, float a3, float a4, float a5, int lane) {
+    const float b0 = swap32_add(a0, a1), b1 = swap32_add(a2, a3), b2 = swap32_add(a4, a5);
+    float c0 = swap16_add(b0, b1);     // rows: a0 a2 a1 a3
+    float c1 = swap16_add(b2, b2);     // rows: a4 a4 a5 a5
+    c0 = row_sum_all(c0);
+    c1 = row_sum_all(c1);
+    return (lane & 15) == 15 ? c0 : c1;
+}
+
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, o, 64));
@@ -261,7 +279,9 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 //         quadrant).  Quadrants the instance's box misses are skipped with a wave-uniform branch, so the
 //         per-pixel arithmetic is the same as with NQ = 1, but the record fetch, the 10-value wave reduction
 //         and the atomic happen once per (instance, tile) instead of once per (instance, quadrant).
-template <int NQ>
+// POSE_ONLY: the caller wants no gradient for colours / opacities (pose tracking against a fixed map): the colour and
+//            opacity sums are neither formed nor reduced -- 6 values instead of 10 through the wave reduction.
+template <int NQ, bool POSE_ONLY>
 __global__ void __launch_bounds__(256) blend_backward_kernel(BlendArgs a, int ntiles,
                                                              const float* __restrict__ final_T,
                                                              const uint32_t* __restrict__ n_contrib,
@@ -305,7 +325,7 @@ __global__ void __launch_bounds__(256) blend_backward_kernel(BlendArgs a, int nt
     }
     const uint32_t maxc = wave_max_u32(lmax);   // wave-uniform
     if (maxc == 0) return;
-    const int slot = reduce10_slot(lane);
+    const int slot = POSE_ONLY ? reduce6_slot(lane) : reduce10_slot(lane);
     const uint32_t end = range.x + maxc;
 
     uint32_t gid_n = 0;
@@ -379,7 +399,8 @@ __global__ void __launch_bounds__(256) blend_backward_kernel(BlendArgs a, int nt
             if (!any_act) continue;
             // ---- 10 wave sums (two swap stages + a ds_swizzle butterfly), then ONE atomic instruction with
             //      10 active lanes covering the Gaussian's 64-byte gradient line
-            const float m = reduce10(s_x, s_y, s_xx, s_xy, s_yy, s_h, s_r, s_g, s_b, s_z, lane);
+            const float m = POSE_ONLY ? reduce6(s_x, s_y, s_xx, s_xy, s_yy, s_z, lane)
+                                      : reduce10(s_x, s_y, s_xx, s_xy, s_yy, s_h, s_r, s_g, s_b, s_z, lane);
             if (slot >= 0) atomicAdd(grad_acc + (size_t)gid * GRAD_FLOATS + slot, m);
         }
     }
@@ -396,15 +417,18 @@ static int tile_per_wave(int) {
 
 int launch_blend_backward(const mgs_camera& cam, const GeometryState& g, const BinningState& b,
                           const ImageState& img, const float* dL_dcolor, const float* dL_ddepth, float* grad_acc,
-                          hipStream_t s) {
+                          bool pose_only, hipStream_t s) {
     const BlendArgs a = make_args(cam, g, b, img);
     const int ntiles = a.gx * tiles_y(a.H);
     if (ntiles == 0) return 0;
     if (tile_per_wave(ntiles))
-        hipLaunchKernelGGL(blend_backward_kernel<4>, dim3((ntiles + 3) / 4), dim3(256), 0, s, a, ntiles, img.final_T,
+        hipLaunchKernelGGL((blend_backward_kernel<4, false>), dim3((ntiles + 3) / 4), dim3(256), 0, s, a, ntiles, img.final_T,
+                           img.n_contrib, dL_dcolor, dL_ddepth, grad_acc);
+    else if (pose_only)
+        hipLaunchKernelGGL((blend_backward_kernel<1, true>), dim3(ntiles), dim3(256), 0, s, a, ntiles, img.final_T,
                            img.n_contrib, dL_dcolor, dL_ddepth, grad_acc);
     else
-        hipLaunchKernelGGL(blend_backward_kernel<1>, dim3(ntiles), dim3(256), 0, s, a, ntiles, img.final_T,
+        hipLaunchKernelGGL((blend_backward_kernel<1, false>), dim3(ntiles), dim3(256), 0, s, a, ntiles, img.final_T,
                            img.n_contrib, dL_dcolor, dL_ddepth, grad_acc);
     MGS_HIP(hipGetLastError());
     return 0;

@@ -198,7 +198,7 @@ int launch_blend_forward(const mgs_camera& cam, const GeometryState& g, const Bi
                          int32_t* n_touched, hipStream_t s);
 int launch_blend_backward(const mgs_camera& cam, const GeometryState& g, const BinningState& b,
                           const ImageState& img, const float* dL_dcolor, const float* dL_ddepth,
-                          float* grad_acc, hipStream_t s);
+                          float* grad_acc, bool pose_only, hipStream_t s);
 struct GeomBackwardArgs {
     const float *means3D, *shs, *colors_precomp, *opacities, *scales, *rotations, *cov3D_precomp;
     const int32_t* radii;

@@ -42,12 +42,26 @@ struct BlendArgs {
 // one-dimensional and its clamped minimiser is closed-form.  Conservative: threshold 1.02 instead of 1 and the
 // rectangle grown by 0.05 px, so a skipped instance has alpha < 1/255 at every pixel of the quadrant under any
 // rounding.  Runs once per lane per 64 instances, so its ~40 instructions cost < 1 per instance.
+//
+// `alive` is the wave's 64-bit mask of pixels that can still use an instance of this step (forward: not yet
+// saturated; backward: the pixel's last contributor is not in front of the step).  An instance whose cull box covers
+// no alive pixel is skipped as well -- in a dense scene most of a tile's depth range is walked for the sake of a few
+// unsaturated pixels, and most instances of those steps sit over pixels that finished long ago.  Exact: a pixel
+// outside the box has alpha < 1/255, a dead pixel ignores every instance.
 __device__ __forceinline__ bool quadrant_hit(const float4 c /* px, py, ex, ey */, const float4 n /* na, nb, nc, . */,
-                                             float qx0, float qy0) {
+                                             float qx0, float qy0, unsigned long long alive) {
     const float x0 = qx0 - 0.05f - c.x, x1 = qx0 + (float)(SUB - 1) + 0.05f - c.x;   // rectangle relative to the centre
     const float y0 = qy0 - 0.05f - c.y, y1 = qy0 + (float)(SUB - 1) + 0.05f - c.y;
     if (c.z < 0.f) return false;                      // opacity < 1/255 (or an empty slot): contributes nowhere
     if (!((c.z >= x0) && (-c.z <= x1) && (c.w >= y0) && (-c.w <= y1))) return false;   // bounding boxes apart
+    {   // pixels (qx0 + i, qy0 + j) inside the box: i in [ix0, ix1], j in [iy0, iy1] (clamped; the box may be huge or NaN-wide)
+        const int ix0 = (int)fminf(8.f, fmaxf(0.f, ceilf(-x0 - c.z - 0.06f))), ix1 = (int)fminf(7.f, fmaxf(-1.f, floorf(-x0 + c.z + 0.06f)));
+        const int iy0 = (int)fminf(8.f, fmaxf(0.f, ceilf(-y0 - c.w - 0.06f))), iy1 = (int)fminf(7.f, fmaxf(-1.f, floorf(-y0 + c.w + 0.06f)));
+        if (ix0 > ix1 || iy0 > iy1) return false;
+        const unsigned long long cols = (unsigned long long)((0xFFu >> (7 - ix1)) & (0xFFu << ix0) & 0xFFu) * 0x0101010101010101ull;
+        const unsigned long long rows = (~0ull >> (8 * (7 - iy1))) & (~0ull << (8 * iy0));
+        if ((cols & rows & alive) == 0ull) return false;
+    }
     if (x0 <= 0.f && x1 >= 0.f && y0 <= 0.f && y1 >= 0.f) return true;                 // centre inside
     if (!(n.x > 0.f) || !(n.z > 0.f)) return true;                                     // no ellipse data: keep
     // v_rcp_f32 (1 ulp) instead of two IEEE divide sequences: the 2 % threshold margin dwarfs the error
@@ -112,7 +126,8 @@ __global__ void __launch_bounds__(256) blend_forward_kernel(BlendArgs a, float* 
         const uint32_t gid_l = gid_n;
         const float4 c = box_n, el = ell_n;
         prefetch(base + WAVE + lane);
-        const bool hit = quadrant_hit(c, el, qx0, qy0);
+        const unsigned long long alive = __builtin_amdgcn_ballot_w64(T != 0.f);      // pixels still blending
+        const bool hit = quadrant_hit(c, el, qx0, qy0, alive);
         unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
         bool all_done = false;
         while (mask) {
@@ -348,7 +363,9 @@ __global__ void __launch_bounds__(256) blend_backward_kernel(BlendArgs a, int nt
         unsigned long long qmask[NQ], mask = 0ull;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            const bool hit = quadrant_hit(c, el, qx0[q], qy0[q]);
+            // pixels whose last contributor is at or behind this step's first instance (1-based position b*64 + 1)
+            const unsigned long long alive = __builtin_amdgcn_ballot_w64(last[q] >= (uint32_t)b * WAVE + 1u);
+            const bool hit = quadrant_hit(c, el, qx0[q], qy0[q], alive);
             qmask[q] = __builtin_amdgcn_ballot_w64(hit);
             mask |= qmask[q];
         }

@@ -125,7 +125,7 @@ def main():
         theta.grad = rho.grad = None
         means2D = torch.zeros_like(xyz, requires_grad=True)
         color, radii, depth, opacity, n_touched = rasterizer(
-            means3D=xyz, means2D=means2D, opacities=opac, colors_precomp=rgb, scales=scaling.repeat(1, 3),
+            means3D=xyz, means2D=means2D, opacities=opac, colors_precomp=rgb, scales=scaling,     # isotropic [P,1], as MonoGS's map
             rotations=rot, theta=theta, rho=rho)
         torch.autograd.backward([color, depth], [g_color, g_depth])
         if bucket is not None:

@@ -51,7 +51,10 @@ typedef struct mgs_camera {
     float scale_modifier;
     int32_t sh_degree;           /* active SH degree (0..3); ignored with colors_precomp */
     int32_t sh_coeffs;           /* M: coefficient triplets per Gaussian in `shs` (0 with colors_precomp) */
-    int32_t reserved;
+    int32_t scale_dim;           /* floats per Gaussian in `scales` / `dL_dscales`: 0 or 3 = (sx, sy, sz); 1 = isotropic --
+                                    the expansion render() does with scales.repeat(1, 3)
+                                    (/root/reference/gaussian_splatting/gaussian_renderer/__init__.py:101-104) and the
+                                    sum of its backward happen inside the kernels */
     const float* bg;             /* [3]  */
     const float* viewmatrix;     /* [16] transposed world->camera */
     const float* projmatrix;     /* [16] transposed P @ T_cw */

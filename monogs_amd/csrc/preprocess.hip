@@ -149,6 +149,7 @@ struct PreArgs {
     int32_t* radii;
     float tanfovx, tanfovy, focal_x, focal_y, mod;
     int P, W, H, gx, gy, deg, M;
+    int iso;                  // scales holds ONE float per Gaussian
     uint32_t* zero_ptr;       // scratch of the depth sort that follows: cleared here instead of by its own launch
     size_t zero_words;
 };
@@ -183,7 +184,8 @@ __global__ void __launch_bounds__(256) preprocess_forward_kernel(PreArgs a) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) cov[k] = a.cov3D[6 * idx + k];
     } else {
-        const float s[3] = {a.scales[3 * idx], a.scales[3 * idx + 1], a.scales[3 * idx + 2]};
+        const float s0 = a.iso ? a.scales[idx] : a.scales[3 * idx];
+        const float s[3] = {s0, a.iso ? s0 : a.scales[3 * idx + 1], a.iso ? s0 : a.scales[3 * idx + 2]};
         const float q[4] = {a.rotations[4 * idx], a.rotations[4 * idx + 1], a.rotations[4 * idx + 2],
                             a.rotations[4 * idx + 3]};
         float Mm[9];
@@ -265,6 +267,7 @@ int launch_preprocess_forward(const mgs_camera& cam, int P, const float* means3D
     a.focal_x = (float)cam.image_width / (2.0f * cam.tanfovx);
     a.focal_y = (float)cam.image_height / (2.0f * cam.tanfovy);
     a.mod = cam.scale_modifier;
+    a.iso = cam.scale_dim == 1;
     a.P = P; a.W = cam.image_width; a.H = cam.image_height;
     a.gx = tiles_x(a.W); a.gy = tiles_y(a.H); a.deg = cam.sh_degree; a.M = cam.sh_coeffs;
     if (P == 0) return 0;
@@ -284,6 +287,7 @@ struct BwdArgs {
     const uint8_t* clamped;
     float tanfovx, tanfovy, focal_x, focal_y, mod;
     int P, W, H, deg, M;
+    int iso;                  // scales / dL_dscales hold ONE float per Gaussian
 };
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -307,7 +311,10 @@ __global__ void __launch_bounds__(256) geom_backward_kernel(BwdArgs a) {
             if (a.g.dL_dopacity) a.g.dL_dopacity[idx] = 0.f;
             if (a.g.dL_dmeans3D) { a.g.dL_dmeans3D[3 * idx] = 0.f; a.g.dL_dmeans3D[3 * idx + 1] = 0.f; a.g.dL_dmeans3D[3 * idx + 2] = 0.f; }
             if (a.g.dL_dcov3D) for (int k = 0; k < 6; ++k) a.g.dL_dcov3D[6 * idx + k] = 0.f;
-            if (a.g.dL_dscales) { a.g.dL_dscales[3 * idx] = 0.f; a.g.dL_dscales[3 * idx + 1] = 0.f; a.g.dL_dscales[3 * idx + 2] = 0.f; }
+            if (a.g.dL_dscales) {
+                if (a.iso) a.g.dL_dscales[idx] = 0.f;
+                else { a.g.dL_dscales[3 * idx] = 0.f; a.g.dL_dscales[3 * idx + 1] = 0.f; a.g.dL_dscales[3 * idx + 2] = 0.f; }
+            }
             if (a.g.dL_drotations) for (int k = 0; k < 4; ++k) a.g.dL_drotations[4 * idx + k] = 0.f;
             if (a.g.dL_dsh) for (int k = 0; k < a.M * 3; ++k) a.g.dL_dsh[(size_t)idx * a.M * 3 + k] = 0.f;
         }
@@ -328,7 +335,8 @@ __global__ void __launch_bounds__(256) geom_backward_kernel(BwdArgs a) {
 #pragma unroll
             for (int k = 0; k < 6; ++k) cov[k] = a.g.cov3D_precomp[6 * idx + k];
         } else {
-            s[0] = a.g.scales[3 * idx]; s[1] = a.g.scales[3 * idx + 1]; s[2] = a.g.scales[3 * idx + 2];
+            if (a.iso) { s[0] = s[1] = s[2] = a.g.scales[idx]; }
+            else { s[0] = a.g.scales[3 * idx]; s[1] = a.g.scales[3 * idx + 1]; s[2] = a.g.scales[3 * idx + 2]; }
             q[0] = a.g.rotations[4 * idx]; q[1] = a.g.rotations[4 * idx + 1];
             q[2] = a.g.rotations[4 * idx + 2]; q[3] = a.g.rotations[4 * idx + 3];
             cov3d_from_scale_rot(s, q, a.mod, cov, Mm);
@@ -520,10 +528,12 @@ __global__ void __launch_bounds__(256) geom_backward_kernel(BwdArgs a) {
                                  2.f * (qx * qz - r * qy), 2.f * (qy * qz + r * qx), 1.f - 2.f * (qx * qx + qy * qy)};
             const float sm[3] = {s[0] * a.mod, s[1] * a.mod, s[2] * a.mod};
             if (a.g.dL_dscales) {
+                float ds[3];
 #pragma unroll
                 for (int j = 0; j < 3; ++j)
-                    a.g.dL_dscales[3 * idx + j] =
-                        a.mod * ((dM[j] * Rm[j] + dM[3 + j] * Rm[3 + j]) + dM[6 + j] * Rm[6 + j]);
+                    ds[j] = a.mod * ((dM[j] * Rm[j] + dM[3 + j] * Rm[3 + j]) + dM[6 + j] * Rm[6 + j]);
+                if (a.iso) a.g.dL_dscales[idx] = (ds[0] + ds[1]) + ds[2];       // backward of the isotropic expansion
+                else { a.g.dL_dscales[3 * idx] = ds[0]; a.g.dL_dscales[3 * idx + 1] = ds[1]; a.g.dL_dscales[3 * idx + 2] = ds[2]; }
             }
             if (a.g.dL_drotations) {
                 float dR[9];
@@ -571,6 +581,7 @@ int launch_geom_backward(const mgs_camera& cam, int P, const GeometryState& g, c
     a.focal_x = (float)cam.image_width / (2.0f * cam.tanfovx);
     a.focal_y = (float)cam.image_height / (2.0f * cam.tanfovy);
     a.mod = cam.scale_modifier;
+    a.iso = cam.scale_dim == 1;
     a.P = P; a.W = cam.image_width; a.H = cam.image_height; a.deg = cam.sh_degree; a.M = cam.sh_coeffs;
     if (P == 0) return 0;
     if (ga.colors_precomp)

@@ -144,20 +144,34 @@ __global__ void __launch_bounds__(RS_THREADS) rs_tile_hist_kernel(const uint32_t
 // ds_bpermute, seven times per step: 8.7 us for 125 k counts).
 __global__ void __launch_bounds__(RS_THREADS) rs_row_scan_kernel(uint32_t* __restrict__ counts, uint32_t tiles,
                                                                  uint32_t* __restrict__ totals /* [256] */) {
-    const int lane = threadIdx.x & 63;
-    const uint32_t d = blockIdx.x * RS_WAVES + (threadIdx.x >> 6);          // 0..255
+    // one WORKGROUP per digit: wave w scans the w-th quarter of the row (64 tiles per step, DPP scan), the quarters are
+    // joined through LDS (a wave per digit walked 1287 tiles in 21 dependent steps: 13 us for the tile sort at C5)
+    __shared__ uint32_t s_part[RS_WAVES];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t d = blockIdx.x;                                          // 0..255
     uint32_t* row = counts + (size_t)d * tiles;
-    uint32_t carry = 0;                                                     // wave-uniform
-    uint32_t next = lane < tiles ? row[lane] : 0u;                          // one chunk in flight ahead of the scan
-    for (uint32_t b0 = 0; b0 < tiles; b0 += WAVE) {
+    const uint32_t per = ((tiles + RS_WAVES - 1) / RS_WAVES + WAVE - 1) / WAVE * WAVE;   // quarter length, multiple of 64
+    const uint32_t lo = min(tiles, (uint32_t)wv * per), hi = min(tiles, lo + per);
+    // pass 1: total of the quarter
+    uint32_t sum = 0;
+    for (uint32_t i = lo + lane; i < hi; i += WAVE) sum += row[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    if (lane == 0) s_part[wv] = sum;
+    __syncthreads();
+    uint32_t carry = 0;                                                     // wave-uniform: tiles before this quarter
+    for (int w = 0; w < wv; ++w) carry += s_part[w];
+    if (threadIdx.x == 0) totals[d] = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+    // pass 2: exclusive scan of the quarter (the re-read hits the cache)
+    uint32_t next = (lo + lane) < hi ? row[lo + lane] : 0u;
+    for (uint32_t b0 = lo; b0 < hi; b0 += WAVE) {
         const uint32_t i = b0 + lane;
         const uint32_t v = next;
-        next = (i + WAVE) < tiles ? row[i + WAVE] : 0u;
+        next = (i + WAVE) < hi ? row[i + WAVE] : 0u;
         const uint32_t incl = wave_incl_scan_dpp(v);
-        if (i < tiles) row[i] = carry + incl - v;
+        if (i < hi) row[i] = carry + incl - v;
         carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     }
-    if (lane == 0) totals[d] = carry;
 }
 
 struct RsPassArgs {
@@ -397,7 +411,7 @@ int radix_sort_pairs(uint32_t* ka, uint32_t* va, uint32_t* kb, uint32_t* vb, uin
             // t.hist[p] receives the 256 digit totals
             hipLaunchKernelGGL(rs_tile_hist_kernel<RS_ITEMS>, dim3(tiles), dim3(RS_THREADS), 0, s, kin, (uint32_t)n, n_dev,
                                a.shift, tiles, counts);
-            hipLaunchKernelGGL(rs_row_scan_kernel, dim3(RS_RADIX / RS_WAVES), dim3(RS_THREADS), 0, s, counts, tiles,
+            hipLaunchKernelGGL(rs_row_scan_kernel, dim3(RS_RADIX), dim3(RS_THREADS), 0, s, counts, tiles,
                                t.hist + p * RS_RADIX);
             hipLaunchKernelGGL((rs_pass_kernel<RS_ITEMS, true>), dim3(tiles), dim3(RS_THREADS), 0, s, a);
         } else if (rs_items(n) == RS_ITEMS_SMALL)

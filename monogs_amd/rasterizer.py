@@ -99,8 +99,9 @@ def _f32(t: torch.Tensor, name: str) -> torch.Tensor:
     return t.contiguous()
 
 
-def _camera(rs: GaussianRasterizationSettings, sh_coeffs: int, keep: list) -> _lib.MgsCamera:
+def _camera(rs: GaussianRasterizationSettings, sh_coeffs: int, keep: list, scale_dim: int = 3) -> _lib.MgsCamera:
     cam = _lib.MgsCamera()
+    cam.scale_dim = int(scale_dim)
     cam.image_height, cam.image_width = int(rs.image_height), int(rs.image_width)
     cam.tanfovx, cam.tanfovy = float(rs.tanfovx), float(rs.tanfovy)
     cam.scale_modifier = float(rs.scale_modifier)
@@ -168,7 +169,10 @@ class _RasterizeGaussians(torch.autograd.Function):
 
         with _device_guard(dev):
             keep = []
-            cam = _camera(rs, M, keep)
+            scale_dim = int(sc_.shape[1]) if sc_ is not None else 3     # [P,1]: isotropic, expanded inside the kernels
+            if scale_dim not in (1, 3):
+                raise Exception("scales must be [P,3] (or [P,1] for an isotropic map)")
+            cam = _camera(rs, M, keep, scale_dim)
             timing = _lib.MgsTiming() if _timing_sink is not None else None
             tref = C.byref(timing) if timing is not None else None
             u8 = dict(dtype=torch.uint8, device=dev)
@@ -223,6 +227,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.raster_settings = rs
         ctx.num_rendered = R
         ctx.sh_coeffs = M
+        ctx.scale_dim = scale_dim
         ctx.has = (sh_ is not None, col_ is not None, sc_ is not None, cov_ is not None,
                    theta is not None, rho is not None)
         dummy = torch.empty(0, device=dev)
@@ -247,7 +252,7 @@ class _RasterizeGaussians(torch.autograd.Function):
 
         with _device_guard(dev):
             keep = []
-            cam = _camera(rs, ctx.sh_coeffs, keep)
+            cam = _camera(rs, ctx.sh_coeffs, keep, ctx.scale_dim)
             f32 = dict(dtype=torch.float32, device=dev)
             g_color = _f32(grad_color, "grad_color") if grad_color is not None else torch.zeros(3, H, W, **f32)
             g_depth = _f32(grad_depth, "grad_depth") if grad_depth is not None else torch.zeros(1, H, W, **f32)
@@ -257,7 +262,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             d_sh = out(need[2] and has_sh, P, max(ctx.sh_coeffs, 1), 3)
             d_col = out(need[3] and has_col, P, 3)
             d_opac = out(need[4], P, 1)
-            d_scales = out(need[5] and has_sr, P, 3)
+            d_scales = out(need[5] and has_sr, P, ctx.scale_dim)
             d_rot = out(need[6] and has_sr, P, 4)
             d_cov = out(need[7] and has_cov, P, 6)
             want_tau = (need[8] and has_theta) or (need[9] and has_rho)

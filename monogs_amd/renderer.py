@@ -53,8 +53,8 @@ def render(viewpoint_camera, cam_intrinsics, means, rotations, scales, opacity, 
         viewmatrix=world_view, projmatrix=full_proj, projmatrix_raw=projection_matrix,
         sh_degree=0, campos=campos, prefiltered=False, debug=False)
 
-    if scales.shape[-1] == 1:          # isotropic map
-        scales = scales.repeat(1, 3)
+    # isotropic map: the reference expands with scales.repeat(1, 3) here (gaussian_renderer/__init__.py:101-104); the
+    # kernels take the [P,1] tensor as it is (mgs_camera.scale_dim = 1) and sum the three gradients themselves
     colors = features if override_color is None else override_color
 
     rasterizer = GaussianRasterizer(raster_settings=raster_settings)

@@ -175,9 +175,7 @@ class TrackingGraph:
         self._r = _r
         dev = proto.device
         with torch.no_grad():
-            sca = gmap.get_scaling.detach()
-            self.map = (gmap.get_xyz.detach(), gmap.get_rotation.detach(),
-                        sca.repeat(1, 3) if sca.shape[-1] == 1 else sca,      # the isotropic expansion, once per map
+            self.map = (gmap.get_xyz.detach(), gmap.get_rotation.detach(), gmap.get_scaling.detach(),   # [P,1]: isotropic
                         gmap.get_opacity.detach(), gmap.get_features.detach())
         self.n_gaussians = int(self.map[0].shape[0])
         self.svp = Viewpoint(-1, torch.zeros_like(proto.rgb), torch.ones_like(proto.depth), dev)

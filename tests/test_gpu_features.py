@@ -390,3 +390,27 @@ def test_pose_only_backward_matches_full(native_lib):
 
     for a, b in zip(run(True), run(False)):
         assert (a - b).norm() <= 2e-5 * b.norm() + 1e-12
+
+
+def test_isotropic_scales_match_repeat(native_lib):
+    """scales [P,1] (mgs_camera.scale_dim = 1) == what render() gets from scales.repeat(1, 3), forward and backward."""
+    from monogs_amd.rasterizer import GaussianRasterizer
+    sc = make_scene(8000, "fr3_office", seed=9, device=DEV)
+    st = _hip_st(sc)
+    gcol, gdep = sc.grad_color.to(DEV), sc.grad_depth.to(DEV)
+
+    def run(iso):
+        m = sc.means3D.clone().requires_grad_(True)
+        s1 = sc.scales.clone().requires_grad_(True)                     # [P,1]
+        r_ = sc.rotations.clone().requires_grad_(True)
+        out = GaussianRasterizer(st)(means3D=m, means2D=torch.zeros_like(m), opacities=sc.opacities, colors_precomp=sc.colors,
+                                     scales=s1 if iso else s1.repeat(1, 3), rotations=r_)
+        ((out[0] * gcol).sum() + (out[2] * gdep).sum()).backward()
+        return out, [m.grad, s1.grad, r_.grad]
+
+    (oa, ga), (ob, gb) = run(True), run(False)
+    for x, y in zip(oa, ob):
+        assert torch.equal(x, y)
+    assert ga[1].shape == (8000, 1)
+    for a, b in zip(ga, gb):
+        assert (a - b).norm() <= 2e-5 * b.norm() + 1e-12

@@ -7,7 +7,8 @@ path, marker = sys.argv[1], sys.argv[2]
 rows = list(csv.DictReader(open(path)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 idx = [i for i, r in enumerate(rows) if marker in r["Kernel_Name"]]
-a, b = idx[-2], idx[-1]
+k = int(sys.argv[3]) if len(sys.argv) > 3 else -1     # which occurrence ends the window (default: the last)
+a, b = idx[k - 1], idx[k]
 t0 = int(rows[a]["End_Timestamp"])
 for r in rows[a + 1:b + 1]:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])

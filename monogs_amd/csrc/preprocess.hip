@@ -303,18 +303,16 @@ __global__ void __launch_bounds__(256) geom_backward_kernel(BwdArgs a) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     float tau[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const bool live = idx < a.P && a.g.radii[idx] > 0;
+    // The [P,3] outputs (means2D, means3D, colours, anisotropic scales) are collected here and stored at the end through a
+    // per-wave LDS transpose: a lane writing its own 12 bytes makes every store instruction touch 12 cache lines a
+    // third each; transposed, each store is 256 contiguous bytes.  Zero for culled Gaussians.
+    float o_m2[2] = {0.f, 0.f}, o_m3[3] = {0.f, 0.f, 0.f}, o_col[3] = {0.f, 0.f, 0.f}, o_sc[3] = {0.f, 0.f, 0.f};
     if (idx < a.P) {
         // defaults for culled Gaussians: every gradient is zero
-        if (a.g.dL_dmeans2D) { a.g.dL_dmeans2D[3 * idx] = 0.f; a.g.dL_dmeans2D[3 * idx + 1] = 0.f; a.g.dL_dmeans2D[3 * idx + 2] = 0.f; }
         if (!live) {
-            if (a.g.dL_dcolors) { a.g.dL_dcolors[3 * idx] = 0.f; a.g.dL_dcolors[3 * idx + 1] = 0.f; a.g.dL_dcolors[3 * idx + 2] = 0.f; }
             if (a.g.dL_dopacity) a.g.dL_dopacity[idx] = 0.f;
-            if (a.g.dL_dmeans3D) { a.g.dL_dmeans3D[3 * idx] = 0.f; a.g.dL_dmeans3D[3 * idx + 1] = 0.f; a.g.dL_dmeans3D[3 * idx + 2] = 0.f; }
             if (a.g.dL_dcov3D) for (int k = 0; k < 6; ++k) a.g.dL_dcov3D[6 * idx + k] = 0.f;
-            if (a.g.dL_dscales) {
-                if (a.iso) a.g.dL_dscales[idx] = 0.f;
-                else { a.g.dL_dscales[3 * idx] = 0.f; a.g.dL_dscales[3 * idx + 1] = 0.f; a.g.dL_dscales[3 * idx + 2] = 0.f; }
-            }
+            if (a.g.dL_dscales && a.iso) a.g.dL_dscales[idx] = 0.f;
             if (a.g.dL_drotations) for (int k = 0; k < 4; ++k) a.g.dL_drotations[4 * idx + k] = 0.f;
             if (a.g.dL_dsh) for (int k = 0; k < a.M * 3; ++k) a.g.dL_dsh[(size_t)idx * a.M * 3 + k] = 0.f;
         }
@@ -403,7 +401,7 @@ __global__ void __launch_bounds__(256) geom_backward_kernel(BwdArgs a) {
         const float gpx = -opq * (qa * ga[G_SX] + qb * ga[G_SY]);
         const float gpy = -opq * (qc * ga[G_SY] + qb * ga[G_SX]);
         const float gnx = gpx * 0.5f * (float)a.W, gny = gpy * 0.5f * (float)a.H;
-        if (a.g.dL_dmeans2D) { a.g.dL_dmeans2D[3 * idx] = gnx; a.g.dL_dmeans2D[3 * idx + 1] = gny; }
+        o_m2[0] = gnx; o_m2[1] = gny;
         float ph[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) ph[k] = dot3p(c.PM[k], c.PM[4 + k], c.PM[8 + k], c.PM[12 + k], x, y, z);
@@ -419,9 +417,7 @@ __global__ void __launch_bounds__(256) geom_backward_kernel(BwdArgs a) {
         // ---- colour
         float gmean_w[3] = {0.f, 0.f, 0.f};   // direct world-space contributions (SH view direction)
         if (!SH) {
-            if (a.g.dL_dcolors) {
-                a.g.dL_dcolors[3 * idx] = ga[G_DR]; a.g.dL_dcolors[3 * idx + 1] = ga[G_DG]; a.g.dL_dcolors[3 * idx + 2] = ga[G_DB];
-            }
+            if (a.g.dL_dcolors) { o_col[0] = ga[G_DR]; o_col[1] = ga[G_DG]; o_col[2] = ga[G_DB]; }
         } else {
             float gc[3] = {ga[G_DR], ga[G_DG], ga[G_DB]};
 #pragma unroll
@@ -492,8 +488,7 @@ __global__ void __launch_bounds__(256) geom_backward_kernel(BwdArgs a) {
         if (a.g.dL_dmeans3D) {
 #pragma unroll
             for (int j = 0; j < 3; ++j)   // (Rv^T gpc)[j] = sum_i Rv(i,j) gpc[i],  Rv(i,j) = V[4*j+i]
-                a.g.dL_dmeans3D[3 * idx + j] =
-                    ((c.V[4 * j] * gpc[0] + c.V[4 * j + 1] * gpc[1]) + c.V[4 * j + 2] * gpc[2]) + gmean_w[j];
+                o_m3[j] = ((c.V[4 * j] * gpc[0] + c.V[4 * j + 1] * gpc[1]) + c.V[4 * j + 2] * gpc[2]) + gmean_w[j];
         }
         // ---- pose:  d p_c / d rho = I,  d p_c / d theta = -[p_c]x,  d Rv(:,j) / d theta = -[Rv(:,j)]x
         tau[0] += gpc[0]; tau[1] += gpc[1]; tau[2] += gpc[2];
@@ -533,7 +528,7 @@ __global__ void __launch_bounds__(256) geom_backward_kernel(BwdArgs a) {
                 for (int j = 0; j < 3; ++j)
                     ds[j] = a.mod * ((dM[j] * Rm[j] + dM[3 + j] * Rm[3 + j]) + dM[6 + j] * Rm[6 + j]);
                 if (a.iso) a.g.dL_dscales[idx] = (ds[0] + ds[1]) + ds[2];       // backward of the isotropic expansion
-                else { a.g.dL_dscales[3 * idx] = ds[0]; a.g.dL_dscales[3 * idx + 1] = ds[1]; a.g.dL_dscales[3 * idx + 2] = ds[2]; }
+                else { o_sc[0] = ds[0]; o_sc[1] = ds[1]; o_sc[2] = ds[2]; }
             }
             if (a.g.dL_drotations) {
                 float dR[9];
@@ -555,6 +550,27 @@ __global__ void __launch_bounds__(256) geom_backward_kernel(BwdArgs a) {
         }
     }
     // ---- block reduction of the 6 pose components, one atomic per block and component
+    {   // ---- transposed stores of the three-float outputs (every lane of the wave takes part)
+        __shared__ float s_stage[4][3 * WAVE];
+        const int lane = threadIdx.x & 63;
+        float* st = s_stage[threadIdx.x >> 6];
+        const size_t base = (size_t)(idx - lane) * 3, limit = (size_t)a.P * 3;
+        auto store3 = [&](float* __restrict__ out, float v0, float v1, float v2) {
+            if (!out) return;                                   // wave-uniform
+            __builtin_amdgcn_wave_barrier();
+            st[3 * lane] = v0; st[3 * lane + 1] = v1; st[3 * lane + 2] = v2;
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const size_t o = base + (size_t)k * WAVE + lane;
+                if (o < limit) out[o] = st[k * WAVE + lane];
+            }
+        };
+        store3(a.g.dL_dmeans2D, o_m2[0], o_m2[1], 0.f);
+        store3(a.g.dL_dmeans3D, o_m3[0], o_m3[1], o_m3[2]);
+        store3(a.g.dL_dcolors, o_col[0], o_col[1], o_col[2]);
+        if (!a.iso) store3(a.g.dL_dscales, o_sc[0], o_sc[1], o_sc[2]);
+    }
     if (a.g.dL_dtau) {
         __shared__ float part[4][6];
         const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;

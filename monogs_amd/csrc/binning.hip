@@ -10,7 +10,8 @@
 // (2) instances emitted in that order, (3) stable sort of the R instances on the tile id only
 // (13 bits at 1080p: 2 radix passes over 8-byte pairs instead of 6 passes over 12-byte pairs).
 // Stability of both sorts makes the result identical to the single 64-bit sort.  The sort itself is
-// the hand-written one-sweep LSD radix sort of radix_sort.hip.
+// the hand-written LSD radix sort of radix_sort.hip.  The last pass of the depth sort also lays the tile
+// rectangles out in depth order, so the scan and duplicate below read everything coalesced.
 #include "common.h"
 
 

@@ -4,14 +4,23 @@
 // (tile id, Gaussian index) instances by tile id.  Replaces upstream's cub::DeviceRadixSort call
 // (SURVEY.md section 2.1 K4).
 //
-// Structure ("one sweep" per 8-bit digit):
+// Two paths, bit-identical results, chosen by size (rs_scanned()):
+//
+// "One sweep" (<= 1 M pairs: every sort of a SLAM-sized map; fewest launches):
 //   * ONE histogram kernel reads the keys once and counts every digit of every pass (each pass kernel
 //     scans its 256 counts into exclusive global bases itself);
-//   * per pass ONE kernel.  A workgroup (256 threads = 4 waves) takes a tile of 4096 pairs, ranks
+//   * per pass ONE kernel.  A workgroup (256 threads = 4 waves) takes a tile of 1024-4096 pairs, ranks
 //     them stably (wave64 __ballot match per digit bit + per-wave LDS counters), publishes its 256
 //     digit counts, obtains the sum of the counts of all EARLIER tiles by decoupled look-back, lays
 //     the tile out digit-by-digit in LDS and writes each digit's run to its final place (coalesced
 //     runs instead of a 256-way scatter).
+// "Pre-scanned offsets" (> 1 M pairs): per pass rs_tile_hist_kernel (digit counts of every tile),
+//   rs_row_scan_kernel (exclusive scan along the tiles of each digit + digit totals) and the same
+//   ranking / scatter kernel reading its offsets from that table -- no waiting between workgroups.  With
+//   hundreds of co-resident tiles the look-back's status traffic and round trips dominated the pass.
+// The last pass can also gather an auxiliary array through the sorted values (aux_out[pos] = aux_in[value]).
+//
+// One-sweep details:
 // Inter-workgroup protocol (MI355X_MICROARCH.md "Workgroup dispatch ... visibility", form R2): every
 // status word is a self-describing 8-byte granule {flag:2, count:62} written by ONE agent-scope
 // relaxed atomic store and polled with agent-scope relaxed atomic loads; no other data crosses

@@ -44,8 +44,12 @@ def get_loss_tracking(render_image, render_depth, render_opacity, viewpoint, inv
 
 
 @torch.no_grad()
-def get_median_depth(depth, mask=None):
+def get_median_depth(depth, mask=None, return_std=False):
+    """/root/reference/utils/slam_utils.py:149-157 (median of the valid depths; optionally their std and the mask)."""
     valid = depth > 0
     if mask is not None:
         valid = torch.logical_and(valid, mask)
-    return depth[valid].median()
+    valid_depth = depth[valid]
+    if return_std:
+        return valid_depth.median(), valid_depth.std(), valid
+    return valid_depth.median()

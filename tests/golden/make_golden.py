@@ -8,6 +8,7 @@ Outputs (data only -- inputs and the reference's outputs):
   camera_pose.npz : getProjectionMatrix / getWorld2View / CameraIntrinsics.FoV / SE3_exp / update_pose
   sh_eval.npz     : eval_sh for degrees 0..3 on seeded inputs
   losses.npz      : get_loss_mapping / get_loss_tracking values and autograd gradients on seeded images
+  median_depth.npz: get_median_depth (value, std, valid mask) on a seeded depth image with holes, with and without a mask
 """
 import math
 import os
@@ -24,7 +25,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 from gaussian_splatting.utils.graphics_utils import getProjectionMatrix, getWorld2View  # noqa: E402
 from gaussian_splatting.utils.sh_utils import eval_sh  # noqa: E402
 from utils.pose_utils import SE3_exp, SO3_exp, V, update_pose  # noqa: E402
-from utils.slam_utils import get_loss_mapping, get_loss_tracking  # noqa: E402
+from utils.slam_utils import get_loss_mapping, get_loss_tracking, get_median_depth  # noqa: E402
 
 INTR = {
     "fr3_office": dict(fx=535.4, fy=539.2, cx=320.1, cy=247.6, W=640, H=480),
@@ -131,8 +132,27 @@ def losses():
     np.savez_compressed(os.path.join(HERE, "losses.npz"), **out)
 
 
+def median_depth():
+    g = torch.Generator().manual_seed(77)
+    depth = torch.rand(1, 48, 64, generator=g) * 5.0
+    depth[torch.rand(1, 48, 64, generator=g) < 0.2] = 0.0           # invalid pixels
+    mask = torch.rand(1, 48, 64, generator=g) < 0.6
+    out = {"depth": depth.numpy(), "mask": mask.numpy()}
+    for tag, m in (("nomask", None), ("mask", mask)):
+        med, std, valid = get_median_depth(depth, m, return_std=True)
+        out[f"median_{tag}"] = np.array([med.item()], dtype=np.float32)
+        out[f"std_{tag}"] = np.array([std.item()], dtype=np.float32)
+        out[f"valid_{tag}"] = valid.numpy()
+        assert float(get_median_depth(depth, m)) == med.item()
+    np.savez_compressed(os.path.join(HERE, "median_depth.npz"), **out)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "median_depth":        # add one fixture without rewriting the others
+        median_depth()
+        sys.exit(0)
     camera_pose()
     sh_eval()
     losses()
+    median_depth()
     print("golden fixtures written to", HERE)

@@ -26,6 +26,10 @@ class GaussianAdam:
         self.exp_avg_sq = [torch.zeros_like(p) for p in self.params]
         self.t_dev = torch.zeros(1, dtype=torch.int32, device=self.params[0].device)
 
+    def set_lr(self, index: int, lr: float):
+        """Learning rate of tensor ``index`` for the following steps (``update_learning_rate`` sets the xyz group's)."""
+        self.lrs[index] = float(lr)
+
     def zero_grad(self, set_to_none=True):
         for p in self.params:
             if set_to_none:
@@ -49,6 +53,23 @@ class GaussianAdam:
 
 
 @torch.no_grad()
+def expon_lr(step: int, lr_init: float, lr_final: float, lr_delay_steps: int = 0, lr_delay_mult: float = 1.0,
+             max_steps: int = 1000000) -> float:
+    """Position learning-rate schedule of ``GaussianModel.update_learning_rate``
+    (/root/reference/gaussian_splatting/scene/gaussian_model.py:451-465 -> ``helper`` in
+    /root/reference/gaussian_splatting/utils/general_utils.py:79-94): log-linear interpolation from ``lr_init`` to
+    ``lr_final`` over ``max_steps`` with an optional eased-in delay factor.  Checked against the reference's own
+    outputs (tests/golden/lr_schedule.npz)."""
+    import math
+    if step < 0 or (lr_init == 0.0 and lr_final == 0.0):
+        return 0.0
+    delay = 1.0
+    if lr_delay_steps > 0:
+        delay = lr_delay_mult + (1.0 - lr_delay_mult) * math.sin(0.5 * math.pi * min(max(step / lr_delay_steps, 0.0), 1.0))
+    t = min(max(step / max_steps, 0.0), 1.0)
+    return delay * math.exp(math.log(lr_init) * (1.0 - t) + math.log(lr_final) * t)
+
+
 def add_densification_stats(viewspace_grad: torch.Tensor, radii: torch.Tensor, xyz_gradient_accum=None, denom=None,
                             max_radii_2d=None):
     """In-place update of the three statistics for one rendered keyframe (visible = radii > 0)."""

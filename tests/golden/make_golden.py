@@ -8,6 +8,7 @@ Outputs (data only -- inputs and the reference's outputs):
   camera_pose.npz : getProjectionMatrix / getWorld2View / CameraIntrinsics.FoV / SE3_exp / update_pose
   sh_eval.npz     : eval_sh for degrees 0..3 on seeded inputs
   losses.npz      : get_loss_mapping / get_loss_tracking values and autograd gradients on seeded images
+  lr_schedule.npz : general_utils.helper (the xyz learning-rate schedule of update_learning_rate)
   median_depth.npz: get_median_depth (value, std, valid mask) on a seeded depth image with holes, with and without a mask
 """
 import math
@@ -147,12 +148,27 @@ def median_depth():
     np.savez_compressed(os.path.join(HERE, "median_depth.npz"), **out)
 
 
+def lr_schedule():
+    from gaussian_splatting.utils.general_utils import helper
+    steps = np.array([-1, 0, 1, 10, 100, 1234, 30000, 999999, 1000000, 2000000], dtype=np.int64)
+    cases = [  # (lr_init, lr_final, lr_delay_steps, lr_delay_mult, max_steps): MonoGS's xyz group and two delay variants
+        (1.6e-4 * 6.0, 1.6e-6 * 6.0, 0, 0.01, 30000),
+        (1.6e-4, 1.6e-6, 500, 0.01, 30000),
+        (0.0, 0.0, 0, 1.0, 1000),
+    ]
+    out = {"steps": steps, "cases": np.array(cases, dtype=np.float64)}
+    for i, (a, b, ds, dm, ms) in enumerate(cases):
+        out[f"lr_{i}"] = np.array([float(helper(int(s_), a, b, int(ds), dm, int(ms))) for s_ in steps], dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, "lr_schedule.npz"), **out)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "median_depth":        # add one fixture without rewriting the others
-        median_depth()
+    if len(sys.argv) > 1 and sys.argv[1] in ("median_depth", "lr_schedule"):   # add one fixture without rewriting the others
+        {"median_depth": median_depth, "lr_schedule": lr_schedule}[sys.argv[1]]()
         sys.exit(0)
     camera_pose()
     sh_eval()
     losses()
     median_depth()
+    lr_schedule()
     print("golden fixtures written to", HERE)

@@ -99,6 +99,7 @@ def main():
     from monogs_amd.window import GradBucket
 
     # the map is shared by all ranks (seed 2); every rank looks at it from its own keyframe pose
+    is_c5 = args.gaussians == 2_000_000 and args.intrinsics == "davis_1080p"
     sc = make_scene(args.gaussians, args.intrinsics, seed=2)
     if rank:
         d = se3_exp(torch.tensor([0.02 * rank, -0.01 * rank, 0.0, 0.0, 0.004 * rank, 0.0]))
@@ -191,7 +192,7 @@ def main():
         both = (b_fwd + b_bwd) / ((stages["blend_fwd_ms"] + stages["blend_bwd_ms"]) * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
+        if is_c5 and os.path.exists(tpath):          # the PMC passes were collected on the C5 workload only
             try:
                 traffic = json.load(open(tpath)).get("blend_backward_bytes_per_launch")
             except Exception:
@@ -261,7 +262,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"C5: {args.gaussians} Gaussians, {W}x{H}, fwd+bwd, seeded synthetic map "
+            "config": {"workload": f"{'C5' if is_c5 else 'custom'}: {args.gaussians} Gaussians, {W}x{H}, fwd+bwd, seeded synthetic map "
                                    f"(SURVEY.md 8d), one keyframe per GPU",
                        "gaussians": args.gaussians, "width": W, "height": H,
                        "instance_count": "device-side (capacity mode, overflow checked)" if sync_free else "host read-back per forward",

@@ -5,10 +5,16 @@
 
 A step is one forward+backward render of BASELINE config 5 (2M Gaussians, 1920x1080, synthetic):
 preprocess, binning, blend, blend backward, per-Gaussian backward with the pose Jacobian.  With
-N > 1 (launched by torch.distributed.run, one rank per GPU) every rank renders its own keyframe of
-the mapping window against the same Gaussians and the ranks all-reduce the Gaussian gradients over
-RCCL (weak scaling: one 1080p keyframe per GPU).  Inputs are resident in HBM before the timed region.
-Rank 0 prints ONE JSON line.
+N > 1 every rank (one per GPU) renders its own keyframe of the mapping window against the same
+Gaussians and the ranks all-reduce the Gaussian gradients over RCCL (weak scaling: one 1080p keyframe
+per GPU).  Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+
+``python bench.py --gpus N`` works as typed: when it is not already running under torch.distributed.run
+it starts N fresh rank processes itself (before anything touches the GPU) and exits with their code; the
+driver's ``python -m torch.distributed.run ... bench.py --gpus N`` form is used as it is.
+
+``--workload c4`` times BASELINE config 4 instead: a mapping iteration over an 8-keyframe window at Replica
+resolution, keyframes sharded over the ranks (`monogs_amd.mapping.WindowMapper`; strong scaling).
 """
 from __future__ import annotations
 
@@ -36,12 +42,56 @@ def parse():
     ap.add_argument("--exact-count", action="store_true",
                     help="read the instance count back every forward (upstream behaviour) instead of capacity mode")
     ap.add_argument("--profile-steps", type=int, default=5, help="steps timed per stage with HIP events")
+    ap.add_argument("--workload", choices=("c5", "c4"), default="c5",
+                    help="c5: one 1080p keyframe per GPU (headline); c4: 8-keyframe Replica mapping window sharded over the GPUs")
+    ap.add_argument("--window", type=int, default=8, help="c4: keyframes in the mapping window")
     return ap.parse_args()
 
 
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` outside torch.distributed.run: start N fresh rank processes (this process has not
+    touched the GPU and never will) and hand their exit code back.  Rank 0's JSON line goes straight to our stdout."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this pool (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(1, args.gpus))))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("[bench] launching", " ".join(cmd), file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
+def csrc_hash() -> str:
+    """Identity of the kernel sources this run was built from (the .git directory does not travel to the GPU box):
+    sha256 over monogs_amd/csrc/* and include/*.  profiles/*.json carry the same stamp; stale files are ignored."""
+    import hashlib
+    h = hashlib.sha256()
+    for d in ("monogs_amd/csrc", "include"):
+        for name in sorted(os.listdir(os.path.join(ROOT, d))):
+            if name.endswith((".hip", ".h", "Makefile")):
+                h.update(name.encode())
+                h.update(open(os.path.join(ROOT, d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def stamped_profile(name: str):
+    """profiles/<name> if it was collected on exactly these kernel sources, else None."""
+    path = os.path.join(ROOT, "profiles", name)
+    try:
+        d = json.load(open(path))
+    except Exception:
+        return None
+    return d if d.get("csrc_sha256") == csrc_hash() else None
+
+
 def cpu_baseline():
-    """The oracle (float32 PyTorch-CPU autograd rasteriser) on a density-preserving crop of the
-    workload: same focal length and generator, 1/4 of the pixels and of the Gaussians (~15 s of CPU work)."""
+    """The oracle (float32 PyTorch-CPU autograd rasteriser) on a density-preserving crop of the workload: same focal
+    length and generator, 1/4 of the pixels and of the Gaussians; one un-timed warm-up pass (thread pool, allocator),
+    then the median of three timed fwd+bwd passes (~20-30 s of CPU work in all)."""
     import torch
 
     from monogs_amd.synthetic import make_scene, scene_settings
@@ -59,12 +109,17 @@ def cpu_baseline():
         cores = os.cpu_count() or 1
     cores = max(1, min(cores, 16))
     torch.set_num_threads(cores)
-    t0 = time.perf_counter()
-    rasterize_autograd(inp, st, sc.grad_color, sc.grad_depth, dtype=torch.float32)
-    dt = time.perf_counter() - t0
+    times = []
+    for i in range(4):
+        t0 = time.perf_counter()
+        rasterize_autograd(inp, st, sc.grad_color, sc.grad_depth, dtype=torch.float32)
+        if i:
+            times.append(time.perf_counter() - t0)
+    dt = sorted(times)[1]
     return {"value": round(intr["W"] * intr["H"] / 1e6 / dt, 5), "unit": "Mpix/s", "cores": cores, "kind": "port",
             "sample": f"500k Gaussians, 960x540 crop of the 1080p workload (same focal length, same per-pixel "
-                      f"density), one fwd+bwd, float32, {dt:.1f} s"}
+                      f"density), fwd+bwd, float32, 1 warm-up + median of 3: {dt:.2f} s "
+                      f"(min {min(times):.2f}, max {max(times):.2f})"}
 
 
 def log(*a):
@@ -72,26 +127,110 @@ def log(*a):
         print("[bench]", *a, file=sys.stderr, flush=True)
 
 
+def bench_c4(args, rank, world, dev, distributed, rehearsal):
+    """BASELINE config 4: one mapping iteration over an 8-keyframe window at Replica resolution (1200x680), the
+    keyframes sharded over the ranks, Gaussians replicated, one gradient all-reduce per iteration
+    (monogs_amd.mapping.WindowMapper = /root/reference/utils/slam_mapper.py:244-500).  Strong scaling: the window is
+    fixed, so at N ranks each renders 8/N keyframes.  Synthetic Replica-like sequence (the dataset is not available)."""
+    import torch
+    import torch.distributed as dist
+
+    from monogs_amd import rasterizer as _rast
+    from monogs_amd.gaussian_map import GaussianMap
+    from monogs_amd.mapping import WindowMapper
+    from monogs_amd.slam_harness import make_sequence
+
+    frames, intr = make_sequence(args.window, "replica", n_gaussians=150_000, device=str(dev))
+    bg = torch.zeros(3, device=dev)
+    gmap = GaussianMap(str(dev))
+    gmap.extend_from_frame(frames[0], intr, downsample=8, init=True, point_size=1.0)       # ~100 k Gaussians
+    for vp in frames:
+        vp.update_RT(vp.R_gt.clone(), vp.T_gt.clone())
+    mapper = WindowMapper(gmap, intr, bg, window_size=args.window)
+    mapper.gaussian_update_every = 10 ** 9       # fixed workload: no densification inside the timed region
+    mapper.gaussian_reset = 10 ** 9
+    P, H, W = len(gmap), intr.height, intr.width
+
+    def fence():
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    log(f"c4 scene ready: P={P} {W}x{H}, window {args.window}, world {world}; warmup {args.warmup}")
+    mapper.optimize_map(frames, iters=1)                 # exact path once: records the capacity hint
+    _rast.set_sync_free(True)
+    mapper.optimize_map(frames, iters=max(0, args.warmup - 1))
+    fence()
+    t0 = time.perf_counter()
+    mapper.optimize_map(frames, iters=args.steps)
+    fence()
+    dt = time.perf_counter() - t0
+    if _rast.check_overflow():
+        raise SystemExit("capacity overflow during the timed region")
+    if distributed:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    # exposed time of the exchanges (separate iterations: the measurement synchronises around each collective)
+    mapper.time_comm, mapper.exposed_comm_s = True, 0.0
+    n_prof = max(1, args.profile_steps)
+    mapper.optimize_map(frames, iters=n_prof)
+    comm_ms = mapper.exposed_comm_s / n_prof * 1e3
+    mapper.sync_poses(frames)
+    in_sync = True
+    if distributed:
+        from monogs_amd.window import replicas_in_sync
+        in_sync = replicas_in_sync(gmap.params())
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        line = {
+            "metric": "mapping-window fwd+bwd Mpix/s (C4)", "value": round(args.steps * args.window * H * W / 1e6 / dt, 2),
+            "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"C4: mapping iteration over a {args.window}-keyframe window, {W}x{H} (Replica intrinsics), "
+                                   f"{P} Gaussians, keyframes sharded k % {world}; render + get_loss_mapping + backward + statistics "
+                                   f"+ gradient all-reduce + fused Adam + pose steps" + (" [REHEARSAL: ranks share a device, gloo]" if rehearsal else ""),
+                       "gaussians": P, "width": W, "height": H, "window": args.window,
+                       "parallelism": f"keyframe-sharded x{world}"},
+            "mapping_iters_per_s": round(args.steps / dt, 2), "exchange_exposed_ms": round(comm_ms, 4),
+            "exchange_bytes": 4 * P * 14 + 4 * P, "replicas_in_sync": bool(in_sync),
+            "roofline": None, "cpu_baseline": None,
+        }
+        print(json.dumps(line), flush=True)
+
+
 def main():
     args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # not under torch.distributed.run yet: spawn the ranks BEFORE torch.cuda / HIP is touched in this process
+        raise SystemExit(self_launch(args))
     import torch
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 "
-                         "--nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N ...")
-    assert torch.cuda.is_available(), "bench.py needs a GPU"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    n_dev = torch.cuda.device_count()          # (does not initialise the GPU)
+    assert n_dev > 0, "bench.py needs a GPU"
+    # Fewer devices than ranks (a one-GPU box): REHEARSAL of the multi-rank path -- ranks share devices and the
+    # collectives run over gloo, staged through host memory (RCCL refuses two ranks on one device).  Flagged in the line.
+    rehearsal = world > n_dev
+    dev = torch.device("cuda", local_rank % n_dev)
+    torch.cuda.set_device(dev)
     distributed = "RANK" in os.environ and "MASTER_PORT" in os.environ     # launched by torch.distributed.run
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+    if args.workload == "c4":
+        return bench_c4(args, rank, world, dev, distributed, rehearsal)
 
     from monogs_amd.camera import se3_exp
     from monogs_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer, collect_timing
@@ -117,7 +256,7 @@ def main():
     rho = torch.zeros(3, device=dev, requires_grad=True)
     g_color, g_depth = sc.grad_color.to(dev), sc.grad_depth.to(dev)
     rasterizer = GaussianRasterizer(st)
-    bucket = GradBucket(params) if distributed else None
+    bucket = GradBucket(params) if (distributed and world > 1) else None
     state = {}
 
     def step():
@@ -190,13 +329,25 @@ def main():
         b_bwd = 44 * R + 24 * HW + 40 * Pv
         ach = b_bwd / (stages["blend_bwd_ms"] * 1e-3) / 1e9
         both = (b_fwd + b_bwd) / ((stages["blend_fwd_ms"] + stages["blend_bwd_ms"]) * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if is_c5 and os.path.exists(tpath):          # the PMC passes were collected on the C5 workload only
-            try:
-                traffic = json.load(open(tpath)).get("blend_backward_bytes_per_launch")
-            except Exception:
-                traffic = None
+        # PMC-derived numbers are attached only when they were collected on exactly these kernel sources (and on C5)
+        traffic = valu = None
+        tj, vj = stamped_profile("traffic.json"), stamped_profile("pmc_valu.json")
+        if is_c5 and tj:
+            traffic = tj.get("blend_backward_bytes_per_launch")
+        if is_c5 and vj and vj.get("blend_backward_kernel"):
+            k = vj["blend_backward_kernel"]
+            # VALU issue peak: 1024 SIMDs, one wave64 VALU instruction per 4 cycles per SIMD (MI355X_MICROARCH.md,
+            # "vector-instruction ISSUE cost"), at the 2.4 GHz maximum clock
+            peak_ips = 1024 * 2.4e9 / 4.0
+            insts = float(k["SQ_INSTS_VALU"])
+            valu = {"valu_wave_insts_per_launch": insts, "survivors_per_launch": k.get("survivors"),
+                    "active_survivors_per_launch": k.get("active_survivors"),
+                    "insts_per_survivor": round(insts / k["survivors"], 2) if k.get("survivors") else None,
+                    "insts_per_active_survivor": round(insts / k["active_survivors"], 2) if k.get("active_survivors") else None,
+                    "achieved_ginst_s": round(insts / (stages["blend_bwd_ms"] * 1e-3) / 1e9, 1),
+                    "peak_ginst_s": round(peak_ips / 1e9, 1),
+                    "frac_of_valu_issue_peak": round(insts / (stages["blend_bwd_ms"] * 1e-3) / peak_ips, 4),
+                    "source": "profiles/pmc_valu.json (rocprofv3 --pmc, stamped with the kernel-source hash)"}
         # measured device-copy ceiling from the same run: 512 MiB device-to-device copy, read + write counted
         src = torch.empty(512 << 20, dtype=torch.uint8, device=dev)
         dst = torch.empty_like(src)
@@ -214,7 +365,8 @@ def main():
             + b_fwd + b_bwd + (44 * P + 40 * Pv + 68 * Pv + 24)
         t_all = sum(stages.values())
         roof = {"bound": "hbm", "kernel": "blend_backward_kernel", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic, "valu": valu,
+                "csrc_sha256": csrc_hash(),
                 "algorithmic_bytes": b_bwd, "avg_ms": stages["blend_bwd_ms"],
                 "blend_fwd_bwd": {"achieved": round(both, 2), "frac": round(both / HBM_PEAK_GBS, 5),
                                   "algorithmic_bytes": b_fwd + b_bwd,
@@ -266,7 +418,8 @@ def main():
                                    f"(SURVEY.md 8d), one keyframe per GPU",
                        "gaussians": args.gaussians, "width": W, "height": H,
                        "instance_count": "device-side (capacity mode, overflow checked)" if sync_free else "host read-back per forward",
-                       "parallelism": f"keyframe-per-gpu x{world}" + (" + RCCL all-reduce of 12 floats/Gaussian" if world > 1 else "")},
+                       "parallelism": f"keyframe-per-gpu x{world}" + (" + RCCL all-reduce of 12 floats/Gaussian" if world > 1 else "")
+                       + (" [REHEARSAL: ranks share a device, collectives over gloo]" if rehearsal else "")},
             "stages_ms": stages, "roofline": roof, "cpu_baseline": cpu, "slam": slam,
         }
         print(json.dumps(line), flush=True)

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define MGS_ABI_VERSION 3
+#define MGS_ABI_VERSION 4
 #define MGS_TILE 16 /* tile edge in pixels; ranges are per 16x16 tile */
 
 /* GaussianRasterizationSettings, minus `prefiltered` / `debug` which are call flags
@@ -217,8 +217,10 @@ int mgs_camera_setup(const float* R, const float* T, const float* projmatrix_raw
 /* ---- Fused Gaussian optimiser step + densification statistics ---------------
  * mgs_adam_step: torch.optim.Adam defaults over n_tensors <= 8 float tensors in one launch (the reference's five
  * groups: /root/reference/gaussian_splatting/scene/gaussian_model.py:398-442).  All tables are HOST arrays of
- * device pointers / sizes / learning rates; grads[t] may be NULL (zero gradient).  `step` is the 1-based step, or
- * step_counter (device int32) is incremented on the device and used instead (hipGraph-capturable).
+ * device pointers / sizes / learning rates; grads[t] may be NULL: that tensor is skipped (parameter, moments and step
+ * count untouched), as torch.optim.Adam skips a parameter whose .grad is None.  `step` is the 1-based step, or
+ * step_counter (device int32[n_tensors], one count per tensor like torch's state["step"]) is incremented on the
+ * device for the tensors that have a gradient and used instead (hipGraph-capturable).
  * mgs_densify_stats: for the Gaussians with radii > 0,  xyz_gradient_accum += ||viewspace_grad[:, :2]||,
  * denom += 1 (gaussian_model.py:888-892), max_radii_2d = max(max_radii_2d, radii) (utils/slam_mapper.py:453-457);
  * any of the three outputs may be NULL. */

@@ -25,27 +25,37 @@ struct AdamArgs {
     int n;
     float beta1, beta2, eps;
     int step;                            // used when step_dev is NULL
-    const int* step_dev;                 // device counter, already incremented for this step
+    const int* step_dev;                 // [n] device counters (one per tensor), already incremented for this step
 };
 
-__global__ void adam_bump_kernel(int* step_dev) { step_dev[0] += 1; }
+// one counter per tensor, as torch keeps state["step"] per parameter: a tensor without a gradient is skipped and
+// its count does not advance (Adam's bias correction then stays in step with torch after map surgery)
+__global__ void adam_bump_kernel(AdamArgs a, int* step_dev) {
+    const int t = threadIdx.x;
+    if (t < a.n && a.grad[t]) step_dev[t] += 1;
+}
 
 __global__ void __launch_bounds__(256) adam_kernel(AdamArgs a) {
-    const int step = a.step_dev ? a.step_dev[0] : a.step;
-    const float bc1 = 1.f - powf(a.beta1, (float)step);
-    const float bc2_sqrt = sqrtf(1.f - powf(a.beta2, (float)step));
+    __shared__ float s_bc1[ADAM_MAX_TENSORS], s_bc2[ADAM_MAX_TENSORS];
+    if ((int)threadIdx.x < a.n) {
+        const int step = a.step_dev ? a.step_dev[threadIdx.x] : a.step;
+        s_bc1[threadIdx.x] = 1.f - powf(a.beta1, (float)step);
+        s_bc2[threadIdx.x] = sqrtf(1.f - powf(a.beta2, (float)step));
+    }
+    __syncthreads();
     const uint64_t total = a.end[a.n - 1];
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
         int t = 0;
         while (i >= a.end[t]) ++t;
+        if (!a.grad[t]) continue;            // no gradient this step: torch.optim.Adam skips the tensor (state untouched)
         const uint64_t j = i - (t ? a.end[t - 1] : 0ull);
-        const float g = a.grad[t] ? a.grad[t][j] : 0.f;
+        const float g = a.grad[t][j];
         const float m = a.beta1 * a.m[t][j] + (1.f - a.beta1) * g;
         const float v = a.beta2 * a.v[t][j] + (1.f - a.beta2) * g * g;
         a.m[t][j] = m;
         a.v[t][j] = v;
-        const float denom = sqrtf(v) / bc2_sqrt + a.eps;
-        a.param[t][j] -= (a.lr[t] / bc1) * (m / denom);
+        const float denom = sqrtf(v) / s_bc2[t] + a.eps;
+        a.param[t][j] -= (a.lr[t] / s_bc1[t]) * (m / denom);
     }
 }
 
@@ -93,7 +103,7 @@ int mgs_adam_step(int32_t n_tensors, float* const* params, const float* const* g
     a.n = n_tensors; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.step = step; a.step_dev = step_counter;
     if (run == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
-    if (step_counter) hipLaunchKernelGGL(adam_bump_kernel, dim3(1), dim3(1), 0, s, step_counter);
+    if (step_counter) hipLaunchKernelGGL(adam_bump_kernel, dim3(1), dim3(ADAM_MAX_TENSORS), 0, s, a, step_counter);
     const uint64_t blocks = (run + 255) / 256;
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, s, a);
     MGS_HIP(hipGetLastError());

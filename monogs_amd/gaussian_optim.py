@@ -24,7 +24,46 @@ class GaussianAdam:
         self.betas, self.eps = betas, float(eps)
         self.exp_avg = [torch.zeros_like(p) for p in self.params]
         self.exp_avg_sq = [torch.zeros_like(p) for p in self.params]
-        self.t_dev = torch.zeros(1, dtype=torch.int32, device=self.params[0].device)
+        self.t_dev = torch.zeros(len(self.params), dtype=torch.int32, device=self.params[0].device)   # per-tensor step counts
+
+    # ---- optimiser-state surgery (map growth / pruning) -----------------------------------------------------
+    # What GaussianModel does to torch.optim.Adam's state when the map changes size
+    # (/root/reference/gaussian_splatting/scene/gaussian_model.py:642-776): the moments of surviving Gaussians are
+    # carried over exactly, new Gaussians start from zero moments, a replaced tensor restarts from zero moments.  The
+    # step count is untouched in all three cases (torch keeps ``state["step"]`` across the surgery as well), and it is
+    # ONE count for all tensors here -- identical to torch as long as every group steps together, which the mapper
+    # does (slam_mapper.py:482).  Each method returns the new leaf tensors (requires_grad) that replace ``params``.
+    @torch.no_grad()
+    def extend(self, new_tensors: Sequence[torch.Tensor]):
+        """``cat_tensors_to_optimizer`` (gaussian_model.py:709-743): append rows, zero moments for them."""
+        assert len(new_tensors) == len(self.params)
+        for i, ext in enumerate(new_tensors):
+            ext = ext.detach().to(self.params[i].dtype)
+            assert ext.shape[1:] == self.params[i].shape[1:], (i, ext.shape, self.params[i].shape)
+            self.params[i] = torch.cat((self.params[i].detach(), ext), 0).requires_grad_(True)
+            self.exp_avg[i] = torch.cat((self.exp_avg[i], torch.zeros_like(ext)), 0)
+            self.exp_avg_sq[i] = torch.cat((self.exp_avg_sq[i], torch.zeros_like(ext)), 0)
+        return list(self.params)
+
+    @torch.no_grad()
+    def prune(self, keep_mask: torch.Tensor):
+        """``_prune_optimizer`` (gaussian_model.py:658-680): keep the rows where ``keep_mask`` is True."""
+        keep_mask = keep_mask.to(self.params[0].device).bool().reshape(-1)
+        assert keep_mask.shape[0] == self.params[0].shape[0]
+        for i in range(len(self.params)):
+            self.params[i] = self.params[i].detach()[keep_mask].requires_grad_(True)
+            self.exp_avg[i] = self.exp_avg[i][keep_mask]
+            self.exp_avg_sq[i] = self.exp_avg_sq[i][keep_mask]
+        return list(self.params)
+
+    @torch.no_grad()
+    def replace(self, index: int, tensor: torch.Tensor):
+        """``replace_tensor_to_optimizer`` (gaussian_model.py:642-656): new values, zero moments (opacity reset)."""
+        assert tensor.shape == self.params[index].shape
+        self.params[index] = tensor.detach().clone().requires_grad_(True)
+        self.exp_avg[index] = torch.zeros_like(self.params[index])
+        self.exp_avg_sq[index] = torch.zeros_like(self.params[index])
+        return self.params[index]
 
     def set_lr(self, index: int, lr: float):
         """Learning rate of tensor ``index`` for the following steps (``update_learning_rate`` sets the xyz group's)."""
@@ -43,6 +82,8 @@ class GaussianAdam:
         n = len(self.params)
         vp = C.c_void_p * n
         grads = [None if p.grad is None else p.grad.contiguous() for p in self.params]
+        if all(g is None for g in grads):       # nothing to do (torch.optim.Adam: every parameter skipped)
+            return
         tab = lambda ts: vp(*[None if t is None else t.data_ptr() for t in ts])  # noqa: E731
         numel = (C.c_uint64 * n)(*[p.numel() for p in self.params])
         lr = (C.c_float * n)(*self.lrs)

@@ -29,7 +29,8 @@ from .knn import distCUDA2
 from .renderer import render
 from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
 from . import fused_losses, slam_losses
-from .gaussian_optim import GaussianAdam, activate
+from .gaussian_map import GaussianMap
+from .gaussian_optim import activate
 from .pose_optim import PoseAdam
 from .synthetic import make_scene
 
@@ -86,70 +87,6 @@ class Viewpoint:
         self.cam_rot_delta.data.zero_()
         self.cam_trans_delta.data.zero_()
         return conv
-
-
-class GaussianMap:
-    """Isotropic RGB map with the reference's activations
-    (/root/reference/gaussian_splatting/scene/gaussian_model.py:84-106)."""
-
-    def __init__(self, device, capturable=False, fused_adam=True):
-        self.device = device
-        self.capturable = capturable        # torch.optim.Adam(capturable=True): step counters on the device (hipGraph)
-        self.fused_adam = fused_adam        # monogs_amd.gaussian_optim.GaussianAdam (one launch, always capturable)
-        e = lambda *s: torch.empty(*s, device=device)  # noqa: E731
-        self._xyz, self._rgb, self._opacity, self._scaling, self._rotation = e(0, 3), e(0, 3), e(0, 1), e(0, 1), e(0, 4)
-        self.optimizer: Optional[torch.optim.Optimizer] = None
-
-    get_xyz = property(lambda s: s._xyz)
-    get_features = property(lambda s: s._rgb)
-    get_opacity = property(lambda s: torch.sigmoid(s._opacity))
-    get_scaling = property(lambda s: torch.exp(s._scaling))
-    get_rotation = property(lambda s: torch.nn.functional.normalize(s._rotation))
-
-    def params(self):
-        return [self._xyz, self._rgb, self._opacity, self._scaling, self._rotation]
-
-    def extend_from_frame(self, vp: Viewpoint, intr: Intrinsics, downsample: int, point_size=0.05, init=False,
-                          render_opacity=None):
-        """Back-project a keyframe's depth into new Gaussians; scale from distCUDA2
-        (/root/reference/gaussian_splatting/scene/gaussian_model.py:121-319, simplified)."""
-        from .keyframe import create_viewpoint_pcd
-        g = torch.Generator(device=self.device).manual_seed(1000 + vp.frame_idx)
-        pw, rgb, scales, rots, opac, _ = create_viewpoint_pcd(
-            vp, intr, render_depth=None if init else vp.depth, render_opacity=None if init else render_opacity, init=init,
-            generator=g, downsample_factor=downsample, point_size=1e9, point_size_max=point_size)   # scale^2 = dist2 * point_size
-        n_new = pw.shape[0]
-        if n_new < 4:
-            return 0
-        new = [pw, rgb, opac, scales, rots]
-        old_opt = self.optimizer
-        old_state = old_opt.state_dict()["state"] if (old_opt is not None and not self.fused_adam) else {}
-        cat = [torch.cat([o.detach(), n], 0).requires_grad_(True) for o, n in zip(self.params(), new)]
-        self._xyz, self._rgb, self._opacity, self._scaling, self._rotation = cat
-        lrs = [1.6e-4 * 6.0, 0.0025, 0.05, 0.001, 0.001]   # position/feature/opacity/scaling/rotation lrs of the reference
-        if self.fused_adam:
-            self.optimizer = GaussianAdam(self.params(), lrs, eps=1e-15)
-            if old_opt is not None:      # carry the moments of the old Gaussians over, zeros for the new ones
-                for i in range(5):
-                    n_old = old_opt.exp_avg[i].shape[0]
-                    self.optimizer.exp_avg[i][:n_old] = old_opt.exp_avg[i]
-                    self.optimizer.exp_avg_sq[i][:n_old] = old_opt.exp_avg_sq[i]
-                self.optimizer.t_dev.copy_(old_opt.t_dev)
-            return n_new
-        groups = [{"params": [p], "lr": lr} for p, lr in zip(self.params(), lrs)]
-        try:       # one multi-tensor kernel per step (the reference uses the default, unfused Adam)
-            self.optimizer = torch.optim.Adam(groups, eps=1e-15, fused=True, capturable=self.capturable)
-        except Exception:
-            self.optimizer = torch.optim.Adam(groups, eps=1e-15, capturable=self.capturable)
-        # carry Adam moments of the old Gaussians over, zeros for the new ones (densification_postfix)
-        for i, p in enumerate(self.params()):
-            st = old_state.get(i)
-            if st is not None:
-                n_new = p.shape[0] - st["exp_avg"].shape[0]
-                pad = lambda t: torch.cat([t, torch.zeros(n_new, *t.shape[1:], device=self.device)], 0)  # noqa: E731
-                self.optimizer.state[p] = dict(step=st["step"], exp_avg=pad(st["exp_avg"]),
-                                               exp_avg_sq=pad(st["exp_avg_sq"]))
-        return n_new
 
 
 def _render(vp, intr, gmap: GaussianMap, bg):

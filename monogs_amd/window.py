@@ -16,7 +16,7 @@ Backend: ``nccl`` (= RCCL over xGMI on MI355X) on GPU, ``gloo`` on CPU for the t
 """
 from __future__ import annotations
 
-from typing import Iterable, List, Optional, Sequence
+from typing import Dict, List, Optional, Sequence
 
 import torch
 import torch.distributed as dist
@@ -25,6 +25,32 @@ import torch.distributed as dist
 def shard_keyframes(n_keyframes: int, rank: int, world: int) -> List[int]:
     """Round-robin ownership: keyframe k belongs to rank k % world."""
     return [k for k in range(n_keyframes) if k % world == rank]
+
+
+def _staged(t: torch.Tensor, group=None) -> bool:
+    """gloo moves host memory only: device tensors are staged through the CPU (the 2-rank rehearsal of the sharded
+    window on a single GPU, tests/test_gpu_window.py).  RCCL (`nccl`) reduces device memory in place."""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def all_reduce_(t: torch.Tensor, op=None, group=None, async_op: bool = False):
+    """In-place all-reduce of ``t`` on whatever backend the group runs (RCCL on GPUs, gloo on CPU / staged)."""
+    op = dist.ReduceOp.SUM if op is None else op
+    if _staged(t, group):
+        h = t.detach().cpu()
+        dist.all_reduce(h, op=op, group=group)
+        t.copy_(h)
+        return None
+    return dist.all_reduce(t, op=op, group=group, async_op=async_op)
+
+
+def all_gather_into_(out: torch.Tensor, inp: torch.Tensor, group=None):
+    if _staged(inp, group):
+        ho = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(ho, inp.detach().cpu(), group=group)
+        out.copy_(ho)
+        return
+    dist.all_gather_into_tensor(out, inp, group=group)
 
 
 # Above this many bytes the gradients are reduced in place, tensor by tensor (5 large collectives),
@@ -84,27 +110,20 @@ class GradBucket:
         return self.buf[:, c:] if self.extra_cols else None
 
     def all_reduce(self, group=None, async_op: bool = False):
+        """SUM over the ranks.  Per-tensor mode issues one asynchronous collective per gradient tensor (public API
+        only; RCCL runs them back to back on its own stream) and waits for all of them unless ``async_op``."""
         if not (dist.is_available() and dist.is_initialized()):
             return None
         if self.per_tensor:
             tensors = [p.grad for p in self.params] + ([self.buf] if self.extra_cols else [])
-            works = None
-            if dist.get_backend(group) == "nccl" and hasattr(dist, "_coalescing_manager"):
-                try:    # one RCCL group launch for all tensors (ncclGroupStart/End), no packing copies
-                    with dist._coalescing_manager(group, device=tensors[0].device, async_ops=True) as cm:
-                        for t in tensors:
-                            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-                    works = [cm]
-                except Exception:
-                    works = None
-            if works is None:
-                works = [dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True) for t in tensors]
+            works = [all_reduce_(t, group=group, async_op=True) for t in tensors]
+            works = [w for w in works if w is not None]
             if async_op:
                 return works
             for w in works:
                 w.wait()
             return None
-        return dist.all_reduce(self.buf, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+        return all_reduce_(self.buf, group=group, async_op=async_op)
 
 
 def allreduce_window_grads(params: Sequence[torch.Tensor], viewspace_grad_norm: Optional[torch.Tensor] = None,
@@ -131,5 +150,110 @@ def allreduce_window_grads(params: Sequence[torch.Tensor], viewspace_grad_norm: 
         if visible_count is not None:
             vs = ex[:, i]
     if max_radii is not None and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(max_radii, op=dist.ReduceOp.MAX, group=group)
+        all_reduce_(max_radii, op=dist.ReduceOp.MAX, group=group)
     return bucket, gn, vs, max_radii
+
+
+# ---- the small exchanges that keep map management identical on every rank -------------------
+def _world(group=None) -> int:
+    return dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+
+
+def _rank(group=None) -> int:
+    return dist.get_rank(group) if (dist.is_available() and dist.is_initialized()) else 0
+
+
+def rows_per_rank(n_keyframes: int, world: int) -> int:
+    return (n_keyframes + world - 1) // world
+
+
+def pack_bits(mask: torch.Tensor) -> torch.Tensor:
+    """bool[..., P] -> uint8[..., ceil(P/8)] (bit i of byte j = element 8j+i)."""
+    P = mask.shape[-1]
+    pad = (-P) % 8
+    m = mask.to(torch.uint8)
+    if pad:
+        m = torch.nn.functional.pad(m, (0, pad))
+    w = torch.tensor([1, 2, 4, 8, 16, 32, 64, 128], dtype=torch.uint8, device=mask.device)
+    return (m.reshape(*mask.shape[:-1], -1, 8) * w).sum(-1, dtype=torch.uint8)
+
+
+def unpack_bits(packed: torch.Tensor, P: int) -> torch.Tensor:
+    w = torch.tensor([1, 2, 4, 8, 16, 32, 64, 128], dtype=torch.uint8, device=packed.device)
+    bits = (packed.unsqueeze(-1) & w) != 0
+    return bits.reshape(*packed.shape[:-1], -1)[..., :P]
+
+
+def all_gather_visibility(local: Dict[int, torch.Tensor], n_keyframes: int, P: int, group=None) -> List[torch.Tensor]:
+    """``occ_aware_visibility_dict[kf] = n_touched_kf > 0`` for EVERY keyframe of the window on every rank
+    (/root/reference/utils/slam_mapper.py:400-404).  ``local`` maps the window positions this rank rendered to
+    bool[P] (or the int n_touched itself); P bits per keyframe travel (all-gather of packed bytes).  Returns a list of
+    bool[P], one per window position."""
+    world, rank = _world(group), _rank(group)
+    dev = next(iter(local.values())).device if local else torch.device("cpu")
+    if world == 1:
+        return [(local[k] > 0) if local[k].dtype != torch.bool else local[k] for k in range(n_keyframes)]
+    rows = rows_per_rank(n_keyframes, world)
+    nb = (P + 7) // 8
+    mine = torch.zeros(rows, nb, dtype=torch.uint8, device=dev)
+    for j, k in enumerate(shard_keyframes(n_keyframes, rank, world)):
+        v = local[k]
+        mine[j] = pack_bits(v if v.dtype == torch.bool else v > 0)
+    allv = torch.empty(world * rows, nb, dtype=torch.uint8, device=dev)
+    all_gather_into_(allv, mine, group=group)
+    return [unpack_bits(allv[(k % world) * rows + k // world], P) for k in range(n_keyframes)]
+
+
+POSE_FLOATS = 14      # R 9, T 3, exposure_a 1, exposure_b 1
+
+
+def all_gather_poses(viewpoints: Sequence, group=None) -> None:
+    """After the window optimisation every rank needs the updated pose and exposure of EVERY keyframe before the map
+    is handed to the front end (/root/reference/utils/slam_mapper.py:553-556).  Keyframe k is owned by rank k % world;
+    the owners' values overwrite the stale copies on the other ranks, in place."""
+    world, rank = _world(group), _rank(group)
+    n = len(viewpoints)
+    if world == 1 or n == 0:
+        return
+    rows = rows_per_rank(n, world)
+    dev = viewpoints[0].R.device
+    mine = torch.zeros(rows, POSE_FLOATS, device=dev)
+    for j, k in enumerate(shard_keyframes(n, rank, world)):
+        vp = viewpoints[k]
+        mine[j] = torch.cat([vp.R.reshape(9), vp.T.reshape(3), vp.exposure_a.detach().reshape(1),
+                             vp.exposure_b.detach().reshape(1)])
+    allp = torch.empty(world * rows, POSE_FLOATS, device=dev)
+    all_gather_into_(allp, mine, group=group)
+    with torch.no_grad():
+        for k, vp in enumerate(viewpoints):
+            if k % world == rank:
+                continue
+            row = allp[(k % world) * rows + k // world]
+            vp.R, vp.T = row[:9].reshape(3, 3).clone(), row[9:12].clone()
+            vp.exposure_a.data.copy_(row[12:13])
+            vp.exposure_b.data.copy_(row[13:14])
+
+
+def split_generator(device, base_seed: int, iteration: int) -> torch.Generator:
+    """The generator ``densify_and_split`` draws its offsets from (/root/reference/gaussian_splatting/scene/
+    gaussian_model.py:793 uses the global RNG): seeded from (base_seed, mapping iteration) only, so replicas that hold
+    bit-identical parameters split into bit-identical children on every rank -- no broadcast needed."""
+    g = torch.Generator(device=device)
+    g.manual_seed((int(base_seed) * 1000003 + int(iteration)) & 0x7FFFFFFFFFFFFFFF)
+    return g
+
+
+def replicas_in_sync(tensors: Sequence[torch.Tensor], group=None) -> bool:
+    """Cheap divergence check for the replicated map: a 64-bit wrap-around checksum of the raw bits of every tensor,
+    compared across ranks with MIN / MAX reductions.  True when every rank holds the same bits."""
+    if _world(group) == 1:
+        return True
+    sums = []
+    for t in tensors:
+        raw = t.detach().contiguous().view(torch.int32).to(torch.int64)
+        sums.append(raw.sum() + 31 * t.shape[0])
+    c = torch.stack(sums)
+    lo, hi = c.clone(), c.clone()
+    all_reduce_(lo, op=dist.ReduceOp.MIN, group=group)
+    all_reduce_(hi, op=dist.ReduceOp.MAX, group=group)
+    return bool((lo == hi).all().item())

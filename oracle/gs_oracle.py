@@ -357,51 +357,60 @@ class OracleOutput(NamedTuple):
     aux: dict
 
 
-def _blend_tile(pix, inside, ids, geom, bg, n_touched, ambiguous):
-    """pix: [256,2] pixel coords; ids: instances of this tile in blend order.
-    Follows the per-pixel loop of SURVEY.md section 2.1 K6 / Appendix A."""
+def _blend_tiles(pix, inside, ids, pad, geom, bg, n_touched, want_ambiguous):
+    """A batch of B tiles at once.  pix: [B,256,2] pixel coords; inside: [B,256]; ids: [B,n] instances of each tile in
+    blend order, padded at the END with 0 where ``pad`` [B,n] is True (a padded slot is skipped by every pixel, so it
+    changes nothing: T, the sums and n_contrib ignore it).  Follows the per-pixel loop of SURVEY.md section 2.1 K6 /
+    Appendix A.  Tiles are batched only to amortise the interpreter: each row of the batch is an independent tile."""
     dtype = pix.dtype
-    xy = geom["xy"][ids]
+    xy = geom["xy"][ids]               # [B,n,2]
     con = geom["conic"][ids]
     op = geom["opacity"][ids]
     col = geom["color"][ids]
     z = geom["depth"][ids]
-    dx = xy[None, :, 0] - pix[:, None, 0]
-    dy = xy[None, :, 1] - pix[:, None, 1]
-    power = -0.5 * (con[None, :, 0] * dx * dx + con[None, :, 2] * dy * dy) - con[None, :, 1] * dx * dy
-    a_raw = op[None, :] * torch.exp(power)
+    dx = xy[:, None, :, 0] - pix[:, :, None, 0]          # [B,256,n]
+    dy = xy[:, None, :, 1] - pix[:, :, None, 1]
+    power = -0.5 * (con[:, None, :, 0] * dx * dx + con[:, None, :, 2] * dy * dy) - con[:, None, :, 1] * dx * dy
+    a_raw = op[:, None, :] * torch.exp(power)
     # reference convention: the 0.99 clamp is ignored by the backward pass (straight-through)
     alpha = a_raw + (torch.clamp_max(a_raw, 0.99) - a_raw).detach()
     with torch.no_grad():
-        skip = (power > 0) | (alpha < 1.0 / 255.0) | (~inside[:, None])
+        skip = (power > 0) | (alpha < 1.0 / 255.0) | (~inside[:, :, None]) | pad[:, None, :]
     a_eff = torch.where(skip, torch.zeros_like(alpha), alpha)
     one_m = 1.0 - a_eff
-    T_incl = torch.cumprod(one_m, dim=1)
-    T_before = torch.cat([torch.ones_like(T_incl[:, :1]), T_incl[:, :-1]], dim=1)
+    T_incl = torch.cumprod(one_m, dim=2)
+    T_before = torch.cat([torch.ones_like(T_incl[:, :, :1]), T_incl[:, :, :-1]], dim=2)
+    amb = None
     with torch.no_grad():
         test_T = T_before * one_m
         stop = (~skip) & (test_T < 0.0001)
-        stopped = torch.cumsum(stop.to(torch.int32), dim=1) > 0       # at and after the stop
+        stopped = torch.cumsum(stop.to(torch.int32), dim=2) > 0       # at and after the stop
         valid = (~skip) & (~stopped)
-        n = ids.shape[0]
-        idx1 = torch.arange(1, n + 1)[None, :].expand_as(valid)
-        n_contrib = torch.where(valid, idx1, torch.zeros_like(idx1)).amax(dim=1)
-        touched = (valid & (test_T > 0.5)).sum(dim=0)
-        n_touched.index_add_(0, ids, touched.to(n_touched.dtype))
-        if ambiguous is not None:
+        n = ids.shape[1]
+        idx1 = torch.arange(1, n + 1)[None, None, :].expand_as(valid)
+        n_contrib = torch.where(valid, idx1, torch.zeros_like(idx1)).amax(dim=2)
+        touched = (valid & (test_T > 0.5)).sum(dim=1)                 # [B,n]
+        n_touched.index_add_(0, ids.reshape(-1), torch.where(pad, torch.zeros_like(touched), touched)
+                             .reshape(-1).to(n_touched.dtype))
+        if want_ambiguous:
             # decisions within a few float32 ulps of their threshold: a different (equally
             # valid) exp / rounding may flip them, so parity tests may exempt these pixels
             near = lambda v, t, r: (v - t).abs() <= r * abs(t)          # noqa: E731
-            amb = (~stopped) & inside[:, None] & (
+            a = (~stopped) & inside[:, :, None] & (~pad[:, None, :]) & (
                 near(alpha.detach(), 1.0 / 255.0, 2e-5) | ((~skip) & near(test_T, 0.0001, 2e-5))
                 | ((~skip) & near(test_T, 0.5, 2e-6)))
-            ambiguous.append(amb.any(dim=1))
+            amb = a.any(dim=2)
     w = torch.where(valid, a_eff * T_before, torch.zeros_like(a_eff))
-    C = w @ col                                               # [256,3]
-    D = w @ z
-    T_final = torch.prod(torch.where(valid, one_m, torch.ones_like(one_m)), dim=1)
-    out_c = C + T_final[:, None] * bg[None, :]
-    return out_c, D, T_final, n_contrib.to(dtype)
+    C = torch.bmm(w, col)                                     # [B,256,3]
+    D = torch.bmm(w, z[:, :, None])[:, :, 0]
+    T_final = torch.prod(torch.where(valid, one_m, torch.ones_like(one_m)), dim=2)
+    out_c = C + T_final[:, :, None] * bg[None, None, :]
+    return out_c, D, T_final, n_contrib.to(dtype), amb
+
+
+# tiles per batch: bounded by the size of one [B,256,n] temporary (elements) and by padding waste
+_BATCH_ELEMS = 1 << 21
+_BATCH_PAD = 1.25
 
 
 def rasterize(means3D, means2D, opacities, settings, *, shs=None, colors_precomp=None,
@@ -426,8 +435,6 @@ def rasterize(means3D, means2D, opacities, settings, *, shs=None, colors_precomp
     ntiles = grid_x * grid_y
     bg = settings.bg.detach().to(dtype)
     n_touched = torch.zeros(P, dtype=torch.int64)
-    ambiguous = [] if want_ambiguous else None
-
     # default (empty tile): colour = bg, depth 0, T = 1
     lx = torch.arange(BLOCK_X).repeat(BLOCK_Y)
     ly = torch.arange(BLOCK_Y).repeat_interleave(BLOCK_X)
@@ -440,22 +447,40 @@ def rasterize(means3D, means2D, opacities, settings, *, shs=None, colors_precomp
     empty_d = torch.zeros(BLOCK_X * BLOCK_Y, dtype=dtype)
     empty_T = torch.ones(BLOCK_X * BLOCK_Y, dtype=dtype)
     empty_b = torch.zeros(BLOCK_X * BLOCK_Y, dtype=torch.bool)
+    lens = (ranges[:, 1] - ranges[:, 0]).tolist()
     for t in range(ntiles):
-        s, e = int(ranges[t, 0]), int(ranges[t, 1])
-        if e <= s:
+        if lens[t] <= 0:
             out_c[t], out_d[t], out_T[t], out_n[t] = empty_c, empty_d, empty_T, empty_d
             amb_tiles[t] = empty_b
-            continue
-        tx, ty = t % grid_x, t // grid_x
-        pxi = tx * BLOCK_X + lx
-        pyi = ty * BLOCK_Y + ly
+    # non-empty tiles, shortest first, in batches of similar list length
+    order = sorted((t for t in range(ntiles) if lens[t] > 0), key=lambda t: lens[t])
+    i = 0
+    while i < len(order):
+        n0 = lens[order[i]]
+        j = i + 1
+        while j < len(order) and lens[order[j]] <= max(n0 * _BATCH_PAD, n0 + 8) \
+                and (j + 1 - i) * 256 * lens[order[j]] <= _BATCH_ELEMS:
+            j += 1
+        batch = order[i:j]
+        i = j
+        n = lens[batch[-1]]
+        B = len(batch)
+        ids = torch.zeros(B, n, dtype=torch.int64)
+        pad = torch.ones(B, n, dtype=torch.bool)
+        for r, t in enumerate(batch):
+            s, e = int(ranges[t, 0]), int(ranges[t, 1])
+            ids[r, :e - s] = point_list[s:e]
+            pad[r, :e - s] = False
+        tt = torch.tensor(batch, dtype=torch.int64)
+        pxi = (tt % grid_x)[:, None] * BLOCK_X + lx[None, :]
+        pyi = (tt // grid_x)[:, None] * BLOCK_Y + ly[None, :]
         inside = (pxi < W) & (pyi < H)
-        pix = torch.stack([pxi, pyi], dim=1).to(dtype)
-        ids = point_list[s:e]
-        out_c[t], out_d[t], out_T[t], out_n[t] = _blend_tile(pix, inside, ids, geom, bg,
-                                                              n_touched, ambiguous)
-        if want_ambiguous:
-            amb_tiles[t] = ambiguous[-1]
+        pix = torch.stack([pxi, pyi], dim=2).to(dtype)
+        c, d, T, nc, amb = _blend_tiles(pix, inside, ids, pad, geom, bg, n_touched, want_ambiguous)
+        for r, t in enumerate(batch):
+            out_c[t], out_d[t], out_T[t], out_n[t] = c[r], d[r], T[r], nc[r]
+            if want_ambiguous:
+                amb_tiles[t] = amb[r]
 
     def _stitch(parts, ch):
         a = torch.stack(parts, dim=0).reshape(grid_y, grid_x, BLOCK_Y, BLOCK_X, ch)

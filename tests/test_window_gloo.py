@@ -1,5 +1,10 @@
-"""Mapping-window sharding over 2 ranks on CPU (gloo): the all-reduced Gaussian gradients equal the
-single-process sum over all keyframes, using the oracle as the per-keyframe renderer stand-in."""
+"""Mapping-window sharding over 2 ranks on CPU (gloo).
+
+* bucket mechanics on seeded random gradient tensors (both bucket modes);
+* the exchanges of SURVEY.md section 8e with the ORACLE as the per-keyframe renderer (the product has no CPU renderer):
+  the all-reduced Gaussian gradients equal the single-process backward of the summed loss, the per-keyframe
+  visibility bits / statistics / poses arrive on every rank.  The same window with the HIP rasteriser runs in
+  tests/test_gpu_window.py."""
 import os
 import socket
 import sys
@@ -95,3 +100,109 @@ def test_single_process_bucket_roundtrip():
         p.grad.zero_()
     b.unpack()
     assert [float(p.grad[0, 0]) for p in params] == [1.0, 2.0, 3.0]
+
+
+# ---- the section-8e exchanges with real (oracle) renders ------------------------------------------------------------
+class _KF:
+    """Minimal keyframe: pose + exposure, as window.all_gather_poses reads and writes them."""
+
+    def __init__(self, k):
+        from oracle import gs_oracle
+        T = gs_oracle.se3_exp(torch.tensor([0.05 * k, -0.03 * k, 0.02 * k, 0.01 * k, 0.02 * k, 0.0], dtype=torch.float64)).float()
+        self.R, self.T = T[:3, :3].contiguous(), T[:3, 3].contiguous()
+        self.exposure_a = torch.nn.Parameter(torch.tensor([0.01 * k]))
+        self.exposure_b = torch.nn.Parameter(torch.tensor([-0.02 * k]))
+
+
+def _oracle_keyframe(params, k):
+    """Render keyframe k of a tiny scene with the oracle and return (loss, viewspace tensor, radii, n_touched)."""
+    from monogs_amd.synthetic import make_scene, scene_settings
+    from oracle import OracleSettings, gs_oracle, rasterize
+    intr = dict(fx=60.0, fy=60.0, cx=32.0, cy=24.0, W=64, H=48)
+    sc = make_scene(params[0].shape[0], intr, seed=5, mean_radius_px=3.0,
+                    pose_tau=(0.1 + 0.02 * k, -0.2, 0.3 - 0.03 * k, 0.05, 0.02 * k, -0.04))
+    st = scene_settings(sc, OracleSettings)
+    xyz, rgb, opac, sca, rot = params
+    m2d = torch.zeros_like(xyz, requires_grad=True)
+    out = rasterize(xyz, m2d, torch.sigmoid(opac), st, colors_precomp=rgb, scales=torch.exp(sca).repeat(1, 3),
+                    rotations=torch.nn.functional.normalize(rot), dtype=torch.float32)
+    loss = (out.color * sc.grad_color).sum() * 1e3 + (out.depth * sc.grad_depth).sum() * 1e3
+    return loss, m2d, out.radii, out.n_touched
+
+
+def _scene_params(P):
+    from monogs_amd.synthetic import make_scene
+    intr = dict(fx=60.0, fy=60.0, cx=32.0, cy=24.0, W=64, H=48)
+    sc = make_scene(P, intr, seed=5, mean_radius_px=3.0)
+    return [sc.means3D.clone().requires_grad_(True), sc.colors.clone().requires_grad_(True),
+            torch.logit(sc.opacities.clamp(0.05, 0.95)).requires_grad_(True), torch.log(sc.scales).requires_grad_(True),
+            sc.rotations.clone().requires_grad_(True)]
+
+
+def _window_local(params, keyframes):
+    """What one rank does for its keyframes: summed loss, one backward, per-keyframe statistics."""
+    P = params[0].shape[0]
+    loss, per_kf = None, {}
+    for k in keyframes:
+        l, m2d, radii, n_touched = _oracle_keyframe(params, k)
+        loss = l if loss is None else loss + l
+        per_kf[k] = (m2d, radii, n_touched)
+    if loss is not None:
+        loss.backward()
+    norm, vis, maxr = torch.zeros(P), torch.zeros(P), torch.zeros(P)
+    for k, (m2d, radii, _) in per_kf.items():
+        v = radii > 0
+        norm[v] += m2d.grad[v, :2].norm(dim=-1)
+        vis[v] += 1
+        maxr[v] = torch.maximum(maxr[v], radii[v].float())
+    return norm, vis, maxr, {k: t[2] for k, t in per_kf.items()}
+
+
+def _exchange_worker(rank, world, port, P, n_kf, out):
+    sys.path.insert(0, ROOT)
+    from monogs_amd import window as W
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    params = _scene_params(P)
+    mine = W.shard_keyframes(n_kf, rank, world)
+    norm, vis, maxr, touched = _window_local(params, mine)
+    _, norm_s, vis_s, maxr_s = W.allreduce_window_grads(params, norm, vis, maxr)
+    vis_bits = W.all_gather_visibility(touched, n_kf, P)
+    kfs = [_KF(k) if k % world == rank else _KF(0) for k in range(n_kf)]      # non-owned copies are stale
+    W.all_gather_poses(kfs)
+    g1, g2 = W.split_generator("cpu", 7, 150), W.split_generator("cpu", 7, 151)
+    torch.save(dict(grads=[p.grad.clone() for p in params], norm=norm_s.clone(), vis=vis_s.clone(), maxr=maxr_s.clone(),
+                    bits=vis_bits, poses=[(k.R, k.T, k.exposure_a.data, k.exposure_b.data) for k in kfs],
+                    draws=(torch.randn(4, generator=g1), torch.randn(4, generator=g2)),
+                    sync=W.replicas_in_sync(params), sync_bad=W.replicas_in_sync([torch.full((3,), float(rank))])),
+               f"{out}.{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_exchanges_with_oracle_renders(tmp_path):
+    P, n_kf, world = 120, 3, 2
+    out = str(tmp_path / "x")
+    mp.spawn(_exchange_worker, args=(world, _free_port(), P, n_kf, out), nprocs=world, join=True)
+    r0, r1 = torch.load(f"{out}.0"), torch.load(f"{out}.1")
+    params = _scene_params(P)
+    norm, vis, maxr, touched = _window_local(params, range(n_kf))         # the single-process window
+    for a, b, p in zip(r0["grads"], r1["grads"], params):
+        assert torch.equal(a, b)                                           # every rank holds the same reduced bits
+        # (isotropic scales: the rotation gradient is identically zero up to rounding noise, hence the absolute term)
+        assert (a - p.grad).norm() <= 1e-5 * p.grad.norm() + 1e-6
+    assert all(p.grad.abs().max() > 1e-4 for p in params[:4])
+    assert torch.allclose(r0["norm"], norm, rtol=1e-5, atol=1e-9) and torch.equal(r0["vis"], vis)
+    assert torch.equal(r0["maxr"], maxr) and torch.equal(r1["maxr"], maxr)
+    for k in range(n_kf):
+        want = touched[k] > 0
+        assert want.any() and torch.equal(r0["bits"][k], want) and torch.equal(r1["bits"][k], want)
+    for k in range(n_kf):
+        ref = _KF(k)
+        for r in (r0, r1):
+            got = r["poses"][k]
+            assert torch.equal(got[0], ref.R) and torch.equal(got[1], ref.T)
+            assert torch.equal(got[2], ref.exposure_a.data) and torch.equal(got[3], ref.exposure_b.data)
+    assert torch.equal(r0["draws"][0], r1["draws"][0]) and not torch.equal(r0["draws"][0], r0["draws"][1])
+    assert r0["sync"] and r1["sync"] and not r0["sync_bad"] and not r1["sync_bad"]

@@ -232,6 +232,7 @@ def main():
     if args.workload == "c4":
         return bench_c4(args, rank, world, dev, distributed, rehearsal)
 
+    from monogs_amd import rasterizer as _rast
     from monogs_amd.camera import se3_exp
     from monogs_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer, collect_timing
     from monogs_amd.synthetic import make_scene, scene_settings
@@ -259,7 +260,7 @@ def main():
     bucket = GradBucket(params) if (distributed and world > 1) else None
     state = {}
 
-    def step():
+    def step(stats=False):
         for p in params:
             p.grad = None
         theta.grad = rho.grad = None
@@ -267,6 +268,8 @@ def main():
         color, radii, depth, opacity, n_touched = rasterizer(
             means3D=xyz, means2D=means2D, opacities=opac, colors_precomp=rgb, scales=scaling,     # isotropic [P,1], as MonoGS's map
             rotations=rot, theta=theta, rho=rho)
+        if stats:
+            state["walk"] = _rast.debug_blend_stats(color)
         torch.autograd.backward([color, depth], [g_color, g_depth])
         if bucket is not None:
             bucket.pack()
@@ -281,7 +284,6 @@ def main():
         torch.cuda.synchronize()
 
     log(f"scene ready: P={args.gaussians} {W}x{H}; warmup {args.warmup}")
-    from monogs_amd import rasterizer as _rast
     step()                                   # first step always exact: it records the capacity hint
     sync_free = not args.exact_count
     _rast.set_sync_free(sync_free)           # steady state: device-side instance count, no host sync per forward
@@ -313,6 +315,8 @@ def main():
             step()
         torch.cuda.synchronize()
     if rank == 0:
+        step(stats=True)                     # (un-timed) what the backward walks: survivors, active survivors, pairs
+        walk = state.get("walk")
         fw = [d for d in sink if d["kind"] == "forward"]
         bw = [d for d in sink if d["kind"] == "backward"]
         avg = lambda rows, k: sum(r[k] for r in rows) / max(1, len(rows))  # noqa: E731
@@ -340,10 +344,10 @@ def main():
             # "vector-instruction ISSUE cost"), at the 2.4 GHz maximum clock
             peak_ips = 1024 * 2.4e9 / 4.0
             insts = float(k["SQ_INSTS_VALU"])
-            valu = {"valu_wave_insts_per_launch": insts, "survivors_per_launch": k.get("survivors"),
-                    "active_survivors_per_launch": k.get("active_survivors"),
-                    "insts_per_survivor": round(insts / k["survivors"], 2) if k.get("survivors") else None,
-                    "insts_per_active_survivor": round(insts / k["active_survivors"], 2) if k.get("active_survivors") else None,
+            valu = {"valu_wave_insts_per_launch": insts, "survivors_per_launch": walk["survivors"],
+                    "active_survivors_per_launch": walk["active_survivors"],
+                    "insts_per_survivor": round(insts / max(1, walk["survivors"]), 2),
+                    "insts_per_active_survivor": round(insts / max(1, walk["active_survivors"]), 2),
                     "achieved_ginst_s": round(insts / (stages["blend_bwd_ms"] * 1e-3) / 1e9, 1),
                     "peak_ginst_s": round(peak_ips / 1e9, 1),
                     "frac_of_valu_issue_peak": round(insts / (stages["blend_bwd_ms"] * 1e-3) / peak_ips, 4),
@@ -375,7 +379,7 @@ def main():
                                "frac": round(b_all / (t_all * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "avg_ms": round(t_all, 4)},
                 "copy_ceiling": {"measured_gbs": round(copy_gbs, 1), "frac_of_copy": round(ach / copy_gbs, 5),
                                  "blend_fwd_bwd_frac_of_copy": round(both / copy_gbs, 5)},
-                "num_rendered": R, "visible": Pv}
+                "num_rendered": R, "visible": Pv, "backward_walk": walk}
 
     log("stages_ms", stages)
     cpu = None

@@ -143,6 +143,15 @@ int mgs_backward(const mgs_camera* cam, int32_t P, uint64_t num_rendered,
                  float* dL_dtau,      /* [6]   */
                  void* backward_scratch, mgs_timing* timing, void* stream);
 
+/* Diagnostic (not on the hot path): counts what the blend backward of the matching forward does, into
+ * stats_dev[8] (device uint64): [0] 64-instance steps walked, [1] instances that pass the per-quadrant cull and are
+ * fetched ("survivors"), [2] survivors with >= 1 active pixel (= wave reductions = atomic instructions),
+ * [3] active (pixel, instance) pairs, [4] inactive survivors that are inactive only because of the depth order,
+ * [5..7] active survivors with <= 2 / 4 / 8 active pixels.  bench.py divides the kernel's VALU instruction count
+ * (rocprofv3 --pmc) by [1] and [2] to report instructions per survivor. */
+int mgs_debug_blend_stats(const mgs_camera* cam, int32_t P, uint64_t num_rendered, const void* geometry,
+                          const void* binning, const void* image, uint64_t* stats_dev, void* stream);
+
 /* visible[P] (1 byte each) = view-space z > 0.2 (upstream markVisible; unused by MonoGS). */
 int mgs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix,
                      uint8_t* visible, void* stream);
@@ -225,8 +234,8 @@ int mgs_camera_setup(const float* R, const float* T, const float* projmatrix_raw
  * denom += 1 (gaussian_model.py:888-892), max_radii_2d = max(max_radii_2d, radii) (utils/slam_mapper.py:453-457);
  * any of the three outputs may be NULL. */
 int mgs_adam_step(int32_t n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
-                  float* const* exp_avg_sq, const uint64_t* numel, const float* lr, float beta1, float beta2,
-                  float eps, int32_t step, int32_t* step_counter, void* stream);
+                  float* const* exp_avg_sq, const uint64_t* numel, const float* lr, double beta1, double beta2,
+                  double eps, int32_t step, int32_t* step_counter, void* stream);
 int mgs_densify_stats(int32_t P, const float* viewspace_grad /* [P,3] */, const int32_t* radii,
                       float* xyz_gradient_accum /* [P] */, float* denom /* [P] */, float* max_radii_2d /* [P] */,
                       void* stream);

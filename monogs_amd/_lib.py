@@ -52,6 +52,7 @@ SIGNATURES = {
     "mgs_backward": (C.c_int, [C.POINTER(MgsCamera), C.c_int32, C.c_uint64] + [C.c_void_p] * 7
                      + [C.c_void_p] * 4 + [C.c_void_p] * 2 + [C.c_void_p] * 9
                      + [C.c_void_p, C.POINTER(MgsTiming), C.c_void_p]),
+    "mgs_debug_blend_stats": (C.c_int, [C.POINTER(MgsCamera), C.c_int32, C.c_uint64] + [C.c_void_p] * 5),
     "mgs_mark_visible": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mgs_loss_scratch_bytes": (C.c_size_t, []),
     "mgs_loss_forward": (C.c_int, [C.c_int32] * 4 + [C.c_float] + [C.c_void_p] * 9 + [C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -60,7 +61,7 @@ SIGNATURES = {
     "mgs_backproject": (C.c_int, [C.c_int32] * 3 + [C.c_void_p] * 6 + [C.c_float] * 4 + [C.c_void_p] * 6),
     "mgs_camera_setup": (C.c_int, [C.c_void_p] * 7),
     "mgs_pose_step": (C.c_int, [C.c_void_p] * 12 + [C.c_int32] + [C.c_float] * 7 + [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
-    "mgs_adam_step": (C.c_int, [C.c_int32] + [C.c_void_p] * 6 + [C.c_float] * 3 + [C.c_int32, C.c_void_p, C.c_void_p]),
+    "mgs_adam_step": (C.c_int, [C.c_int32] + [C.c_void_p] * 6 + [C.c_double] * 3 + [C.c_int32, C.c_void_p, C.c_void_p]),
     "mgs_densify_stats": (C.c_int, [C.c_int32] + [C.c_void_p] * 6),
     "mgs_activate_forward": (C.c_int, [C.c_int32, C.c_int32] + [C.c_void_p] * 7),
     "mgs_activate_backward": (C.c_int, [C.c_int32, C.c_int32] + [C.c_void_p] * 10),

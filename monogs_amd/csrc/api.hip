@@ -287,6 +287,20 @@ int mgs_backward(const mgs_camera* cam, int32_t P, uint64_t R, const float* mean
     return 0;
 }
 
+int mgs_debug_blend_stats(const mgs_camera* cam, int32_t P, uint64_t R, const void* geometry, const void* binning,
+                           const void* image, uint64_t* stats_dev, void* stream) {
+    if (check_cam(cam)) return 1;
+    if (!geometry || !image || !stats_dev || (R > 0 && !binning)) { set_error("bad arguments"); return 1; }
+    hipStream_t s = (hipStream_t)stream;
+    MGS_HIP(zero_fill(stats_dev, 8 * sizeof(uint64_t), s));
+    if (P == 0 || R == 0) return 0;
+    const int W = cam->image_width, H = cam->image_height;
+    GeometryState g = GeometryState::carve(const_cast<void*>(geometry), P);
+    ImageState img = ImageState::carve(const_cast<void*>(image), W, H);
+    BinningState b = BinningState::carve(const_cast<void*>(binning), R, W, H);
+    return launch_blend_backward_stats(*cam, g, b, img, (unsigned long long*)stats_dev, s);
+}
+
 int mgs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix,
                      uint8_t* visible, void* stream) {
     (void)projmatrix;

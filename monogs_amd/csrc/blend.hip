@@ -20,7 +20,6 @@
 // alpha < 1/255 and the per-pixel rule would have skipped it too.
 #include "common.h"
 
-#include <stdlib.h>
 
 namespace mgs {
 
@@ -289,14 +288,13 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
     return v;
 }
 
-// NQ = 1: a wave owns ONE 8x8 quadrant of its tile (4 waves per tile; best when the image has few tiles).
-// NQ = 4: a wave owns the WHOLE 16x16 tile, four pixels per lane (lane l holds local pixel l of each
-//         quadrant).  Quadrants the instance's box misses are skipped with a wave-uniform branch, so the
-//         per-pixel arithmetic is the same as with NQ = 1, but the record fetch, the 10-value wave reduction
-//         and the atomic happen once per (instance, tile) instead of once per (instance, quadrant).
 // POSE_ONLY: the caller wants no gradient for colours / opacities (pose tracking against a fixed map): the colour and
 //            opacity sums are neither formed nor reduced -- 6 values instead of 10 through the wave reduction.
-template <int NQ, bool POSE_ONLY>
+// (Round 2 measured a batched reduction staged through LDS -- permlane32 swap, one ds_write_b32 per register pair, a
+//  flush every 3 survivors in which each lane sums a 16-float segment -- against this in-register one: 20 % fewer VALU
+//  instructions, but the batched atomics (3 gradient lines per instruction, or 3 instructions back to back) were no
+//  longer hidden: 0.60 ms against 0.51 ms at C5, 0.48 ms with the atomics removed.  DESIGN.md section 4.)
+template <bool POSE_ONLY>
 __global__ void __launch_bounds__(256) blend_backward_kernel(BlendArgs a, int ntiles,
                                                              const float* __restrict__ final_T,
                                                              const uint32_t* __restrict__ n_contrib,
@@ -304,7 +302,7 @@ __global__ void __launch_bounds__(256) blend_backward_kernel(BlendArgs a, int nt
                                                              const float* __restrict__ dL_ddepth,
                                                              float* __restrict__ grad_acc) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int tile = NQ == 1 ? (int)blockIdx.x : (int)blockIdx.x * 4 + wave;
+    const int tile = (int)blockIdx.x;
     if (tile >= ntiles) return;
     const int tx = tile % a.gx, ty = tile / a.gx;
     const uint2 range = a.ranges[tile];
@@ -312,36 +310,29 @@ __global__ void __launch_bounds__(256) blend_backward_kernel(BlendArgs a, int nt
     const size_t HW = (size_t)a.H * a.W;
     const float bg0 = a.bg[0], bg1 = a.bg[1], bg2 = a.bg[2];
 
-    // per-pixel state, one set per quadrant handled by this wave
-    float pxf[NQ], pyf[NQ], qx0[NQ], qy0[NQ], T_final[NQ], g0[NQ], g1[NQ], g2[NQ], gd[NQ], bgT[NQ];
-    float T[NQ], A[NQ], last_alpha[NQ], last_q[NQ];
-    uint32_t last[NQ];
-    uint32_t lmax = 0;
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        const int quad = NQ == 1 ? wave : q;
-        const int qx0i = tx * TILE + (quad & 1) * SUB, qy0i = ty * TILE + (quad >> 1) * SUB;
-        const int pxi = qx0i + (lane & 7), pyi = qy0i + (lane >> 3);
-        const bool inside = pxi < a.W && pyi < a.H;
-        const size_t pix = (size_t)pyi * a.W + pxi;
-        pxf[q] = (float)pxi; pyf[q] = (float)pyi; qx0[q] = (float)qx0i; qy0[q] = (float)qy0i;
-        T_final[q] = inside ? final_T[pix] : 0.f;
-        last[q] = inside ? n_contrib[pix] : 0u;
-        g0[q] = inside ? dL_dcolor[pix] : 0.f;
-        g1[q] = inside ? dL_dcolor[HW + pix] : 0.f;
-        g2[q] = inside ? dL_dcolor[2 * HW + pix] : 0.f;
-        gd[q] = inside ? dL_ddepth[pix] : 0.f;
-        bgT[q] = -T_final[q] * (bg0 * g0[q] + bg1 * g1[q] + bg2 * g2[q]);   // background term, per pixel
-        T[q] = T_final[q];
-        A[q] = 0.f;           // sum over channels of (colour behind) * dL/dpixel, blended back to front
-        last_alpha[q] = 0.f;
-        last_q[q] = 0.f;
-        lmax = max(lmax, last[q]);
-    }
-    const uint32_t maxc = wave_max_u32(lmax);   // wave-uniform
+    // per-pixel state
+    const int qx0i = tx * TILE + (wave & 1) * SUB, qy0i = ty * TILE + (wave >> 1) * SUB;
+    const int pxi = qx0i + (lane & 7), pyi = qy0i + (lane >> 3);
+    const bool inside = pxi < a.W && pyi < a.H;
+    const size_t pix = (size_t)pyi * a.W + pxi;
+    const float pxf = (float)pxi, pyf = (float)pyi, qx0 = (float)qx0i, qy0 = (float)qy0i;
+    const float T_final = inside ? final_T[pix] : 0.f;
+    const uint32_t last = inside ? n_contrib[pix] : 0u;
+    const float g0 = inside ? dL_dcolor[pix] : 0.f;
+    const float g1 = inside ? dL_dcolor[HW + pix] : 0.f;
+    const float g2 = inside ? dL_dcolor[2 * HW + pix] : 0.f;
+    const float gd = inside ? dL_ddepth[pix] : 0.f;
+    const float bgT = -T_final * (bg0 * g0 + bg1 * g1 + bg2 * g2);   // background term, per pixel
+    // T: transmittance in front of the instance being processed.  Bk: sum over channels of (colour blended BEHIND the
+    // instance) * dL/dpixel -- the recursion  Bk <- alpha q + (1 - alpha) Bk  folded over the instances already
+    // walked (upstream keeps last_alpha / last_color and applies the same update one instance late).  Both updates
+    // are the identity for alpha = 0, so an inactive lane needs no select on its state.
+    float T = T_final, Bk = 0.f;
+    const uint32_t maxc = wave_max_u32(last);   // wave-uniform
     if (maxc == 0) return;
-    const int slot = POSE_ONLY ? reduce6_slot(lane) : reduce10_slot(lane);
     const uint32_t end = range.x + maxc;
+
+    const int slot = POSE_ONLY ? reduce6_slot(lane) : reduce10_slot(lane);
 
     uint32_t gid_n = 0;
     float4 box_n = make_float4(0.f, 0.f, -1.f, -1.f), ell_n = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -360,60 +351,37 @@ __global__ void __launch_bounds__(256) blend_backward_kernel(BlendArgs a, int nt
         const uint32_t gid_l = gid_n;
         const float4 c = box_n, el = ell_n;
         prefetch(b - 1);
-        unsigned long long qmask[NQ], mask = 0ull;
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            // pixels whose last contributor is at or behind this step's first instance (1-based position b*64 + 1)
-            const unsigned long long alive = __builtin_amdgcn_ballot_w64(last[q] >= (uint32_t)b * WAVE + 1u);
-            const bool hit = quadrant_hit(c, el, qx0[q], qy0[q], alive);
-            qmask[q] = __builtin_amdgcn_ballot_w64(hit);
-            mask |= qmask[q];
-        }
+        // pixels whose last contributor is at or behind this step's first instance (1-based position b*64 + 1)
+        const unsigned long long alive = __builtin_amdgcn_ballot_w64(last >= (uint32_t)b * WAVE + 1u);
+        unsigned long long mask = __builtin_amdgcn_ballot_w64(quadrant_hit(c, el, qx0, qy0, alive));
         while (mask) {
             const int j = 63 - __builtin_clzll(mask);
             mask &= ~(1ull << j);
             const uint32_t k = (uint32_t)b * WAVE + (uint32_t)j + 1u;     // 1-based position in the tile list
             const uint32_t gid = bcast(gid_l, j);
             const Rec g = fetch(a, gid);
+            const float dx = g.px - pxf, dy = g.py - pyf;
+            const float power = dx * (g.ca * dx + g.cb * dy) + (g.cc * dy) * dy;   // log2 of the Gaussian falloff
+            const float G = __builtin_amdgcn_exp2f(power);
+            const float alpha = fminf(0.99f, g.op * G);
+            const bool act = (k <= last) && !(power > 0.f) && !(alpha < 1.0f / 255.0f);
+            if (__builtin_amdgcn_ballot_w64(act) == 0ull) continue;
+            // Everything below runs for all 64 lanes; an inactive lane has alpha = 0: it contributes exact zeros
+            // (w = 0, h = 0) and its state passes through (T * rcp(1) = T, Bk + 0 * diff = Bk).
+            const float a_eff = act ? alpha : 0.f;
+            const float inv = __builtin_amdgcn_rcpf(1.f - a_eff);   // v_rcp_f32, not the IEEE divide sequence
+            const float Tn = T * inv;
+            const float qq = (g.r * g0 + g.g * g1) + (g.b * g2 + g.z * gd);
+            const float diff = qq - Bk;
+            const float dL_dalpha = diff * Tn + bgT * inv;
+            Bk = Bk + a_eff * diff;
+            T = Tn;
+            const float w = a_eff * Tn;
+            const float h = act ? G * dL_dalpha : 0.f;   // g.op and the conic are applied per Gaussian later
+            const float hx = h * dx, hy = h * dy;
             // partial sums of this instance over the wave's pixels (see the G_S* slots in common.h)
-            float s_x = 0.f, s_y = 0.f, s_xx = 0.f, s_xy = 0.f, s_yy = 0.f, s_h = 0.f;
-            float s_r = 0.f, s_g = 0.f, s_b = 0.f, s_z = 0.f;
-            bool any_act = false;
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                if (NQ > 1 && ((qmask[q] >> j) & 1ull) == 0ull) continue;      // wave-uniform: box misses this quadrant
-                const float dx = g.px - pxf[q], dy = g.py - pyf[q];
-                const float power = dx * (g.ca * dx + g.cb * dy) + (g.cc * dy) * dy;   // log2 of the Gaussian falloff
-                const float G = __builtin_amdgcn_exp2f(power);
-                const float alpha = fminf(0.99f, g.op * G);
-                const bool act = (k <= last[q]) && !(power > 0.f) && !(alpha < 1.0f / 255.0f);
-                if (__builtin_amdgcn_ballot_w64(act) == 0ull) continue;
-                any_act = true;
-                // Everything below runs for all 64 lanes; an inactive lane contributes exact zeros
-                // (w = 0, h = 0) and keeps its state.
-                const float inv = __builtin_amdgcn_rcpf(1.f - alpha);   // v_rcp_f32, not the IEEE divide sequence
-                const float Tn = T[q] * inv;
-                const float qq = (g.r * g0[q] + g.g * g1[q]) + (g.b * g2[q] + g.z * gd[q]);
-                const float An = A[q] + last_alpha[q] * (last_q[q] - A[q]);   // = la*lq + (1-la)*A
-                const float dL_dalpha = (qq - An) * Tn + bgT[q] * inv;
-                const float w = act ? alpha * Tn : 0.f;
-                const float h = act ? G * dL_dalpha : 0.f;   // g.op and the conic are applied per Gaussian later
-                T[q] = act ? Tn : T[q];
-                A[q] = act ? An : A[q];
-                last_q[q] = act ? qq : last_q[q];
-                last_alpha[q] = act ? alpha : last_alpha[q];
-                const float hx = h * dx, hy = h * dy;
-                if (NQ == 1) {          // a single quadrant: plain assignment, no accumulate
-                    s_x = hx; s_y = hy; s_h = h;
-                    s_xx = hx * dx; s_xy = hx * dy; s_yy = hy * dy;
-                    s_r = w * g0[q]; s_g = w * g1[q]; s_b = w * g2[q]; s_z = w * gd[q];
-                } else {
-                    s_x += hx; s_y += hy; s_h += h;
-                    s_xx += hx * dx; s_xy += hx * dy; s_yy += hy * dy;
-                    s_r += w * g0[q]; s_g += w * g1[q]; s_b += w * g2[q]; s_z += w * gd[q];
-                }
-            }
-            if (!any_act) continue;
+            const float s_x = hx, s_y = hy, s_xx = hx * dx, s_xy = hx * dy, s_yy = hy * dy, s_h = h;
+            const float s_r = w * g0, s_g = w * g1, s_b = w * g2, s_z = w * gd;
             // ---- 10 wave sums (two swap stages + a ds_swizzle butterfly), then ONE atomic instruction with
             //      10 active lanes covering the Gaussian's 64-byte gradient line
             const float m = POSE_ONLY ? reduce6(s_x, s_y, s_xx, s_xy, s_yy, s_z, lane)
@@ -423,29 +391,96 @@ __global__ void __launch_bounds__(256) blend_backward_kernel(BlendArgs a, int nt
     }
 }
 
-// Measured on MI355X (round 1): the wave-per-tile variant is SLOWER than wave-per-quadrant at every size
-// tried (C5 1080p / 2 M: 0.63 vs 0.59 ms; VGA / 100 k: 0.148 vs 0.092 ms) -- 91 VGPRs (5 waves per SIMD instead
-// of 8), walks bounded by the tile's deepest pixel instead of the quadrant's, and only 8160 long-running
-// waves.  It stays as an opt-in experiment (MGS_TILE_PER_WAVE=1) with parity coverage; the default is NQ = 1.
-static int tile_per_wave(int) {
-    const char* e = getenv("MGS_TILE_PER_WAVE");
-    return e && e[0] == '1';
+// ---- diagnostic: what the backward walk does, counted (not on the hot path; mgs_debug_blend_stats) --------------
+// The same walk, cull and per-pixel activity test as blend_backward_kernel<1, *>, with counters instead of gradient
+// arithmetic: stats[0] steps of 64 instances, [1] instances that pass the quadrant cull and are fetched ("survivors"),
+// [2] survivors with at least one active pixel ("active survivors" = wave reductions = atomic instructions),
+// [3] active (pixel, instance) pairs, [4] inactive survivors whose cull box holds no pixel with k <= last (depth
+// order, not geometry), [5..7] active survivors with <= 2 / <= 4 / <= 8 active pixels.
+__global__ void __launch_bounds__(256) blend_backward_stats_kernel(BlendArgs a, int ntiles,
+                                                                   const uint32_t* __restrict__ n_contrib,
+                                                                   unsigned long long* __restrict__ stats) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tile = (int)blockIdx.x;
+    if (tile >= ntiles) return;
+    const int tx = tile % a.gx, ty = tile / a.gx;
+    const uint2 range = a.ranges[tile];
+    if (range.y <= range.x) return;
+    const int qx0i = tx * TILE + (wave & 1) * SUB, qy0i = ty * TILE + (wave >> 1) * SUB;
+    const int pxi = qx0i + (lane & 7), pyi = qy0i + (lane >> 3);
+    const bool inside = pxi < a.W && pyi < a.H;
+    const float pxf = (float)pxi, pyf = (float)pyi, qx0 = (float)qx0i, qy0 = (float)qy0i;
+    const uint32_t last = inside ? n_contrib[(size_t)pyi * a.W + pxi] : 0u;
+    const uint32_t maxc = wave_max_u32(last);
+    if (maxc == 0) return;
+    const uint32_t end = range.x + maxc;
+    unsigned long long c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int b = (int)((maxc - 1) / WAVE); b >= 0; --b) {
+        const uint32_t i = range.x + (uint32_t)b * WAVE + lane;
+        uint32_t gid_l = 0;
+        float4 box = make_float4(0.f, 0.f, -1.f, -1.f), el = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < end) {
+            gid_l = a.point_list[i];
+            box = a.rec[(size_t)gid_l * 4];
+            el = a.rec[(size_t)gid_l * 4 + 3];
+        }
+        const unsigned long long alive = __builtin_amdgcn_ballot_w64(last >= (uint32_t)b * WAVE + 1u);
+        unsigned long long mask = __builtin_amdgcn_ballot_w64(quadrant_hit(box, el, qx0, qy0, alive));
+        c[0] += 1;
+        c[1] += __popcll(mask);
+        while (mask) {
+            const int j = 63 - __builtin_clzll(mask);
+            mask &= ~(1ull << j);
+            const uint32_t k = (uint32_t)b * WAVE + (uint32_t)j + 1u;
+            const Rec g = fetch(a, bcast(gid_l, j));
+            const float dx = g.px - pxf, dy = g.py - pyf;
+            const float power = dx * (g.ca * dx + g.cb * dy) + (g.cc * dy) * dy;
+            const float alpha = fminf(0.99f, g.op * __builtin_amdgcn_exp2f(power));
+            const bool geo = !(power > 0.f) && !(alpha < 1.0f / 255.0f);
+            const unsigned long long act = __builtin_amdgcn_ballot_w64(geo && k <= last);
+            const int n = __popcll(act);
+            if (n == 0) {
+                if (__builtin_amdgcn_ballot_w64(geo) != 0ull) c[4] += 1;
+                continue;
+            }
+            c[2] += 1;
+            c[3] += n;
+            c[5] += n <= 2;
+            c[6] += n <= 4;
+            c[7] += n <= 8;
+        }
+    }
+    if (lane < 8) {
+        unsigned long long v = c[0];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) v = lane == q ? c[q] : v;
+        atomicAdd(stats + lane, v);
+    }
 }
 
+int launch_blend_backward_stats(const mgs_camera& cam, const GeometryState& g, const BinningState& b,
+                                const ImageState& img, unsigned long long* stats, hipStream_t s) {
+    const BlendArgs a = make_args(cam, g, b, img);
+    const int ntiles = a.gx * tiles_y(a.H);
+    if (ntiles == 0) return 0;
+    hipLaunchKernelGGL(blend_backward_stats_kernel, dim3(ntiles), dim3(256), 0, s, a, ntiles, img.n_contrib, stats);
+    MGS_HIP(hipGetLastError());
+    return 0;
+}
+
+// (The wave-per-tile and half-tile-per-wave variants of round 1 lost at every size and are gone; DESIGN.md section 4
+//  keeps their measurements.)
 int launch_blend_backward(const mgs_camera& cam, const GeometryState& g, const BinningState& b,
                           const ImageState& img, const float* dL_dcolor, const float* dL_ddepth, float* grad_acc,
                           bool pose_only, hipStream_t s) {
     const BlendArgs a = make_args(cam, g, b, img);
     const int ntiles = a.gx * tiles_y(a.H);
     if (ntiles == 0) return 0;
-    if (tile_per_wave(ntiles))
-        hipLaunchKernelGGL((blend_backward_kernel<4, false>), dim3((ntiles + 3) / 4), dim3(256), 0, s, a, ntiles, img.final_T,
-                           img.n_contrib, dL_dcolor, dL_ddepth, grad_acc);
-    else if (pose_only)
-        hipLaunchKernelGGL((blend_backward_kernel<1, true>), dim3(ntiles), dim3(256), 0, s, a, ntiles, img.final_T,
+    if (pose_only)
+        hipLaunchKernelGGL((blend_backward_kernel<true>), dim3(ntiles), dim3(256), 0, s, a, ntiles, img.final_T,
                            img.n_contrib, dL_dcolor, dL_ddepth, grad_acc);
     else
-        hipLaunchKernelGGL((blend_backward_kernel<1, false>), dim3(ntiles), dim3(256), 0, s, a, ntiles, img.final_T,
+        hipLaunchKernelGGL((blend_backward_kernel<false>), dim3(ntiles), dim3(256), 0, s, a, ntiles, img.final_T,
                            img.n_contrib, dL_dcolor, dL_ddepth, grad_acc);
     MGS_HIP(hipGetLastError());
     return 0;

@@ -23,7 +23,8 @@ struct AdamArgs {
     uint64_t end[ADAM_MAX_TENSORS];      // exclusive prefix end of each tensor in the flattened index space
     float lr[ADAM_MAX_TENSORS];
     int n;
-    float beta1, beta2, eps;
+    double beta1, beta2;                 // doubles, as torch keeps them: 1 - beta and the bias corrections are formed in double
+    float eps;
     int step;                            // used when step_dev is NULL
     const int* step_dev;                 // [n] device counters (one per tensor), already incremented for this step
 };
@@ -39,19 +40,20 @@ __global__ void __launch_bounds__(256) adam_kernel(AdamArgs a) {
     __shared__ float s_bc1[ADAM_MAX_TENSORS], s_bc2[ADAM_MAX_TENSORS];
     if ((int)threadIdx.x < a.n) {
         const int step = a.step_dev ? a.step_dev[threadIdx.x] : a.step;
-        s_bc1[threadIdx.x] = 1.f - powf(a.beta1, (float)step);
-        s_bc2[threadIdx.x] = sqrtf(1.f - powf(a.beta2, (float)step));
+        s_bc1[threadIdx.x] = (float)(1.0 - pow(a.beta1, (double)step));
+        s_bc2[threadIdx.x] = (float)sqrt(1.0 - pow(a.beta2, (double)step));
     }
     __syncthreads();
     const uint64_t total = a.end[a.n - 1];
+    const float b1 = (float)a.beta1, b2 = (float)a.beta2, w1 = (float)(1.0 - a.beta1), w2 = (float)(1.0 - a.beta2);
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
         int t = 0;
         while (i >= a.end[t]) ++t;
         if (!a.grad[t]) continue;            // no gradient this step: torch.optim.Adam skips the tensor (state untouched)
         const uint64_t j = i - (t ? a.end[t - 1] : 0ull);
         const float g = a.grad[t][j];
-        const float m = a.beta1 * a.m[t][j] + (1.f - a.beta1) * g;
-        const float v = a.beta2 * a.v[t][j] + (1.f - a.beta2) * g * g;
+        const float m = b1 * a.m[t][j] + w1 * g;
+        const float v = b2 * a.v[t][j] + w2 * g * g;
         a.m[t][j] = m;
         a.v[t][j] = v;
         const float denom = sqrtf(v) / s_bc2[t] + a.eps;
@@ -82,8 +84,8 @@ using namespace mgs;
 extern "C" {
 
 int mgs_adam_step(int32_t n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
-                  float* const* exp_avg_sq, const uint64_t* numel, const float* lr, float beta1, float beta2,
-                  float eps, int32_t step, int32_t* step_counter, void* stream) {
+                  float* const* exp_avg_sq, const uint64_t* numel, const float* lr, double beta1, double beta2,
+                  double eps, int32_t step, int32_t* step_counter, void* stream) {
     if (n_tensors < 1 || n_tensors > ADAM_MAX_TENSORS) { set_error("mgs_adam_step: 1..8 tensors"); return 1; }
     if (!params || !grads || !exp_avg || !exp_avg_sq || !numel || !lr) { set_error("mgs_adam_step: NULL table"); return 1; }
     if (!step_counter && step < 1) { set_error("step is 1-based"); return 1; }
@@ -100,7 +102,7 @@ int mgs_adam_step(int32_t n_tensors, float* const* params, const float* const* g
         a.end[t] = run;
         a.lr[t] = on ? lr[t] : 0.f;
     }
-    a.n = n_tensors; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.step = step; a.step_dev = step_counter;
+    a.n = n_tensors; a.beta1 = beta1; a.beta2 = beta2; a.eps = (float)eps; a.step = step; a.step_dev = step_counter;
     if (run == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     if (step_counter) hipLaunchKernelGGL(adam_bump_kernel, dim3(1), dim3(ADAM_MAX_TENSORS), 0, s, a, step_counter);

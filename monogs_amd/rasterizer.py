@@ -289,6 +289,26 @@ class _RasterizeGaussians(torch.autograd.Function):
         return (d_means3D, d_means2D, d_sh, d_col, d_opac, d_scales, d_rot, d_cov, d_theta, d_rho, None)
 
 
+def debug_blend_stats(color: torch.Tensor) -> dict:
+    """Diagnostic: what the blend backward of the forward that produced ``color`` walks, fetches and reduces
+    (``mgs_debug_blend_stats``; call before ``backward()`` frees the saved scratch).  Synchronises."""
+    fn = color.grad_fn
+    if fn is None or not hasattr(fn, "raster_settings"):
+        raise RuntimeError("debug_blend_stats needs the colour image of a differentiable rasteriser forward")
+    lib = _lib.load()
+    means3D, _, _, _, _, _, _, _, geom, binning, img = fn.saved_tensors
+    keep = []
+    cam = _camera(fn.raster_settings, fn.sh_coeffs, keep, fn.scale_dim)
+    out = torch.zeros(8, dtype=torch.int64, device=means3D.device)
+    with _device_guard(means3D.device):
+        _lib.check(lib.mgs_debug_blend_stats(C.byref(cam), means3D.shape[0], fn.num_rendered, geom.data_ptr(),
+                                             binning.data_ptr(), img.data_ptr(), out.data_ptr(), _stream()),
+                   "mgs_debug_blend_stats")
+    v = out.tolist()
+    return dict(steps=v[0], survivors=v[1], active_survivors=v[2], active_pairs=v[3], inactive_by_depth_order=v[4],
+                active_le2=v[5], active_le4=v[6], active_le8=v[7])
+
+
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                         theta, rho, raster_settings):
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,

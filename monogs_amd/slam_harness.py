@@ -239,6 +239,7 @@ def run_slam(n_frames=12, intrinsics="fr3_office", tracking_itr_num=100, mapping
     bg = torch.zeros(3, device=device)
     gmap = GaussianMap(device, capturable=graph_mapping)
     window: List[Viewpoint] = []
+    per_frame, map_loss = [], []      # (frame, tracking iterations) ; (first, last) mapping loss of every eager window call
     stats = dict(kf_extend_s=0.0, map_capture_s=0.0, map_replay_s=0.0, map_replay_iters=0, track_capture_s=0.0, track_s=0.0, track_iters=0, tracked=0, map_s=0.0, map_iters=0, keyframes=0, renders=0)
 
     def sync():
@@ -294,13 +295,15 @@ def run_slam(n_frames=12, intrinsics="fr3_office", tracking_itr_num=100, mapping
             _r.clear_graph_flags()
             del graph
             return
-        for _ in range(iters):
+        first_last = [None, None]
+        for it_m in range(iters):
             loss = 0
             for vp in window:
                 pkg = _render(vp, intr, gmap, bg)
                 loss = loss + get_loss_mapping(pkg["render"], pkg["depth"], vp, init=init)
                 stats["renders"] += 1
             loss.backward()
+            first_last[0 if it_m == 0 else 1] = loss.detach()
             with torch.no_grad():
                 gmap.optimizer.step()
                 gmap.optimizer.zero_grad(set_to_none=True)
@@ -313,6 +316,7 @@ def run_slam(n_frames=12, intrinsics="fr3_office", tracking_itr_num=100, mapping
                     pa.step_and_retract(sync=False)
                     pa.zero_grad()
             stats["map_iters"] += 1
+        map_loss.append(tuple(first_last))
 
     for i, vp in enumerate(frames):
         if i == 0:
@@ -338,6 +342,7 @@ def run_slam(n_frames=12, intrinsics="fr3_office", tracking_itr_num=100, mapping
             stats["track_iters"] += n_it
             stats["renders"] += n_it
             stats["tracked"] += 1
+            per_frame.append((i, n_it))
             loss = torch.zeros(())
             for p in gmap.params():
                 p.grad = None
@@ -349,6 +354,7 @@ def run_slam(n_frames=12, intrinsics="fr3_office", tracking_itr_num=100, mapping
             opt = torch.optim.Adam([{"params": [vp.cam_rot_delta], "lr": 0.003}, {"params": [vp.cam_trans_delta], "lr": 0.001},
                                     {"params": [vp.exposure_a], "lr": 0.01}, {"params": [vp.exposure_b], "lr": 0.01}])
         sync(); t0 = time.perf_counter()
+        n_eager = 0
         for it in range(0 if graph_tracking else tracking_itr_num):
             pkg = _render(vp, intr, gmap, bg)
             opt.zero_grad()
@@ -362,11 +368,13 @@ def run_slam(n_frames=12, intrinsics="fr3_office", tracking_itr_num=100, mapping
                     conv = vp.retract()
             stats["track_iters"] += 1
             stats["renders"] += 1
+            n_eager += 1
             if conv:
                 break
         if not graph_tracking:
             sync(); stats["track_s"] += time.perf_counter() - t0
             stats["tracked"] += 1
+            per_frame.append((i, n_eager))
         for p in gmap.params():
             p.grad = None
         # ---- keyframe + mapping
@@ -409,6 +417,12 @@ def run_slam(n_frames=12, intrinsics="fr3_office", tracking_itr_num=100, mapping
                                            if stats["map_replay_iters"] else None),
                kf_extend_ms=1e3 * stats["kf_extend_s"] / max(stats["keyframes"] - 1, 1),
                ate_rmse_m=float(torch.sqrt((err ** 2).mean())),
+               track_iters_per_frame=per_frame,
+               poses=[(f.R.detach().cpu().clone(), f.T.detach().cpu().clone()) for f in frames],
+               position_error_m=[float(e) for e in err],
+               camera_centers=[(-(f.R.t() @ f.T)).cpu() for f in frames],
+               camera_centers_gt=[(-(f.R_gt.t() @ f.T_gt)).cpu() for f in frames],
+               map_loss=[(float(a), float(b)) for a, b in map_loss if a is not None and b is not None],
                fused_losses=bool(fused_losses_on), fused_pose=bool(fused_pose_on), graph_tracking=bool(graph_tracking), graph_mapping=bool(graph_mapping),
                config=dict(tracking_itr_num=tracking_itr_num, mapping_itr_num=mapping_itr_num,
                            window_size=window_size, kf_interval=kf_interval, init_itr_num=init_itr_num))

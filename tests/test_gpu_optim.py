@@ -19,14 +19,113 @@ def test_gaussian_adam_matches_torch_adam(native_lib):
         for pa, pb in zip(a, b):
             gr = torch.randn(*pa.shape, generator=g).to(DEV) * (10.0 ** (-it / 4))
             if it == 5:
-                gr.zero_()                       # zero gradients still decay the moments and move the parameter
+                gr.zero_()                       # explicit zero gradients still decay the moments and move the parameter
             pa.grad, pb.grad = gr.clone(), gr.clone()
         fused.step()
         ref.step()
         for pa, pb in zip(a, b):
             # a few float32 ulps per step (different but equivalent operation order), accumulated over 12 steps
             assert torch.allclose(pa, pb, rtol=1e-5, atol=3e-6), (it, (pa - pb).abs().max())
-    assert int(fused.t_dev.item()) == 12
+    assert fused.t_dev.tolist() == [12] * 5
+
+
+def _reference_surgery(opt, names):
+    """The reference's optimiser-state surgery, restated on torch.optim.Adam for the check below
+    (/root/reference/gaussian_splatting/scene/gaussian_model.py:642-743)."""
+    def group(name):
+        return next(g for g in opt.param_groups if g["name"] == name)
+
+    def cat(ext):                                   # cat_tensors_to_optimizer
+        for n in names:
+            g = group(n)
+            st = opt.state.get(g["params"][0])
+            st["exp_avg"] = torch.cat((st["exp_avg"], torch.zeros_like(ext[n])), 0)
+            st["exp_avg_sq"] = torch.cat((st["exp_avg_sq"], torch.zeros_like(ext[n])), 0)
+            del opt.state[g["params"][0]]
+            g["params"][0] = torch.nn.Parameter(torch.cat((g["params"][0], ext[n]), 0).requires_grad_(True))
+            opt.state[g["params"][0]] = st
+
+    def prune(mask):                                # _prune_optimizer
+        for n in names:
+            g = group(n)
+            st = opt.state.get(g["params"][0])
+            st["exp_avg"], st["exp_avg_sq"] = st["exp_avg"][mask], st["exp_avg_sq"][mask]
+            del opt.state[g["params"][0]]
+            g["params"][0] = torch.nn.Parameter(g["params"][0][mask].requires_grad_(True))
+            opt.state[g["params"][0]] = st
+
+    def replace(name, tensor):                      # replace_tensor_to_optimizer
+        g = group(name)
+        st = opt.state.get(g["params"][0])
+        st["exp_avg"], st["exp_avg_sq"] = torch.zeros_like(tensor), torch.zeros_like(tensor)
+        del opt.state[g["params"][0]]
+        g["params"][0] = torch.nn.Parameter(tensor.requires_grad_(True))
+        opt.state[g["params"][0]] = st
+    return cat, prune, replace
+
+
+def test_adam_state_surgery_matches_torch(native_lib):
+    """extend / prune / replace carry the moments and step counts exactly as the reference's surgery on
+    torch.optim.Adam does: same parameters after steps interleaved with a cat, a prune and an opacity-style replace
+    (the replaced tensor has no gradient on the step that follows -- torch skips it, and so does the fused step)."""
+    from monogs_amd.gaussian_optim import GaussianAdam
+    names = ["xyz", "f_dc", "opacity", "scaling", "rotation"]
+    widths = [3, 3, 1, 1, 4]
+    lrs = [1.6e-4 * 6.0, 0.0025, 0.05, 0.001, 0.001]
+    g = torch.Generator().manual_seed(3)
+    rnd = lambda n, w: torch.randn(n, w, generator=g).to(DEV)  # noqa: E731
+    P = 3000
+    a = [rnd(P, w).requires_grad_(True) for w in widths]
+    fused = GaussianAdam(a, lrs)
+    ref = torch.optim.Adam([{"params": [torch.nn.Parameter(t.detach().clone())], "lr": lr, "name": n}
+                            for t, lr, n in zip(a, lrs, names)], lr=0.0, eps=1e-15)
+    cat, prune, replace = _reference_surgery(ref, names)
+
+    def ref_params():
+        return [next(gr for gr in ref.param_groups if gr["name"] == n)["params"][0] for n in names]
+
+    def step(skip=()):
+        for i, (pa, pb) in enumerate(zip(fused.params, ref_params())):
+            if i in skip:
+                pa.grad = pb.grad = None
+                continue
+            gr = torch.randn(*pa.shape, generator=g).to(DEV)
+            pa.grad, pb.grad = gr.clone(), gr.clone()
+        fused.step()
+        ref.step()
+
+    def check(tag):
+        for n, pa, pb in zip(names, fused.params, ref_params()):
+            assert pa.shape == pb.shape, (tag, n)
+            assert torch.allclose(pa, pb, rtol=1e-5, atol=3e-6), (tag, n, (pa - pb).abs().max())
+        for i, n in enumerate(names):
+            st = ref.state[ref_params()[i]]
+            assert torch.allclose(fused.exp_avg[i], st["exp_avg"], rtol=1e-5, atol=1e-7), (tag, n)
+            assert torch.allclose(fused.exp_avg_sq[i], st["exp_avg_sq"], rtol=1e-5, atol=1e-9), (tag, n)
+            assert int(fused.t_dev[i]) == int(st["step"]), (tag, n)
+
+    for _ in range(3):
+        step()
+    check("start")
+    ext = {n: rnd(500, w) for n, w in zip(names, widths)}           # densification_postfix
+    fused.extend([ext[n] for n in names]); cat(ext)
+    assert fused.params[0].shape[0] == P + 500 and fused.params[0].requires_grad and fused.params[0].is_leaf
+    step(); step()
+    check("after extend")
+    mask = (torch.rand(P + 500, generator=g) > 0.3).to(DEV)        # prune_points
+    fused.prune(mask); prune(mask)
+    step()
+    check("after prune")
+    new_op = rnd(int(mask.sum()), 1)                                # reset_opacity*
+    fused.replace(2, new_op); replace("opacity", new_op.clone())
+    step(skip=(2,))          # the mapper steps right after the reset: the new opacity tensor has no gradient yet
+    check("after replace (opacity skipped)")
+    assert int(fused.t_dev[2]) == int(fused.t_dev[0]) - 1
+    step(); step()
+    check("end")
+    fused.zero_grad()
+    fused.step()             # no gradients at all: nothing moves, no count advances
+    check("all grads None")
 
 
 def test_densification_stats(native_lib):

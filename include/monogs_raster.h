@@ -109,13 +109,31 @@ int mgs_forward_preprocess(const mgs_camera* cam, int32_t P,
 int mgs_forward_render(const mgs_camera* cam, int32_t P, uint64_t num_rendered,
                        void* geometry, void* binning, void* image,
                        float* out_color, float* out_depth, float* out_opacity, int32_t* n_touched,
+                       uint32_t* status /* device, optional: MGS_STATUS_* bits of this forward */,
                        mgs_timing* timing, void* stream);
+
+/* Status word of a forward (device uint32, written by the forward's own kernels; 0 = clean).  The hand-written radix
+ * sort bounds every inter-workgroup wait; a wait that runs out raises a flag instead of hanging, and the sorted order
+ * (hence the blend order) is then invalid.  mgs_forward_preprocess reports a depth-sort timeout itself when it
+ * synchronises (num_rendered != NULL); everything else arrives here and is read by the caller at a sync point of its
+ * choice (monogs_amd.rasterizer.check_overflow). */
+#define MGS_STATUS_CAPACITY_OVERFLOW 1u   /* capacity mode: instances were dropped */
+#define MGS_STATUS_DEPTH_SORT_TIMEOUT 2u  /* look-back spin of the depth sort timed out */
+#define MGS_STATUS_TILE_SORT_TIMEOUT 4u   /* look-back spin of the tile sort timed out */
+
+/* Test knob: the bound of the look-back spin (device-wide, all later sorts); 0xFFFFFFFF restores the default. */
+int mgs_debug_set_radix_spin_limit(uint32_t limit);
+/* Test knobs that force an algorithm path whatever the problem size (process-wide; -1 restores the default):
+ * "radix_scanned" (0 = one-sweep look-back, 1 = pre-scanned offsets), "knn_grid_min" (Morton-box kNN from this many
+ * points).  Nothing on the launch path consults the environment. */
+int mgs_debug_set_option(const char* name, int64_t value);
 
 /* Forward, stage 2 without a host-side instance count ("capacity mode"): call mgs_forward_preprocess with
  * num_rendered = NULL (no read-back, no stream sync), size the binning scratch with
  * mgs_binning_bytes(capacity, W, H) for a caller-chosen capacity (e.g. 1.5x the previous frame's count), and the
  * kernels read the live count min(R, capacity) on the device.  If R > capacity the surplus instances are dropped
- * and *overflow (device uint32, optional) is set to 1: the caller must re-render with a larger capacity.  The
+ * and MGS_STATUS_CAPACITY_OVERFLOW is set in *overflow (device uint32, optional; the forward's status word, which
+ * also receives the sort-timeout bits): the caller must re-render with a larger capacity.  The
  * whole forward + backward then contains no host synchronisation and can be captured in a hipGraph.
  * Pass the same `capacity` as num_rendered to mgs_backward. */
 int mgs_forward_render_capacity(const mgs_camera* cam, int32_t P, uint64_t capacity,

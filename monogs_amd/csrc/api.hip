@@ -200,16 +200,15 @@ static int forward_render_impl(const mgs_camera* cam, int32_t P, uint64_t R, boo
     StageTimer tm(s, timing != nullptr);
     const bool cap = capacity && binning;
     if (cap) n_dev = b.count;
-    else if (overflow) MGS_HIP(zero_fill(overflow, sizeof(uint32_t), s));
     tm.mark();
     // (also zeroes n_touched, the tile ranges and the scratch of the tile sort; in capacity mode it publishes the
     //  clamped live count and the overflow flag; with R == 0 it emits nothing)
     if (int rc = launch_duplicate(*cam, P, g, b, capacity ? R : (R > 0 ? 0xFFFFFFFFull : 0ull), n_touched, img, R,
-                                  tile_bits(W, H), cap ? b.count : nullptr, cap ? overflow : nullptr, s)) return rc;
+                                  tile_bits(W, H), cap ? b.count : nullptr, overflow, s)) return rc;
     tm.mark();
     if (int rc = launch_sort(b, R, tile_bits(W, H), s, n_dev)) return rc;
     tm.mark();
-    if (int rc = launch_ranges(b, R, img, tiles_x(W) * tiles_y(H), s, n_dev)) return rc;
+    if (int rc = launch_ranges(b, R, img, tiles_x(W) * tiles_y(H), tile_bits(W, H), s, n_dev, overflow)) return rc;
     tm.mark();
     if (int rc = launch_blend_forward(*cam, g, b, img, out_color, out_depth, out_opacity, n_touched, s)) return rc;
     tm.mark();
@@ -225,9 +224,9 @@ static int forward_render_impl(const mgs_camera* cam, int32_t P, uint64_t R, boo
 
 int mgs_forward_render(const mgs_camera* cam, int32_t P, uint64_t R, void* geometry, void* binning, void* image,
                        float* out_color, float* out_depth, float* out_opacity, int32_t* n_touched,
-                       mgs_timing* timing, void* stream) {
+                       uint32_t* status, mgs_timing* timing, void* stream) {
     return forward_render_impl(cam, P, R, false, geometry, binning, image, out_color, out_depth, out_opacity, n_touched,
-                               nullptr, timing, stream);
+                               status, timing, stream);
 }
 
 int mgs_forward_render_capacity(const mgs_camera* cam, int32_t P, uint64_t capacity, void* geometry, void* binning,
@@ -299,6 +298,15 @@ int mgs_debug_blend_stats(const mgs_camera* cam, int32_t P, uint64_t R, const vo
     ImageState img = ImageState::carve(const_cast<void*>(image), W, H);
     BinningState b = BinningState::carve(const_cast<void*>(binning), R, W, H);
     return launch_blend_backward_stats(*cam, g, b, img, (unsigned long long*)stats_dev, s);
+}
+
+int mgs_debug_set_radix_spin_limit(uint32_t limit) { return set_radix_spin_limit(limit); }
+
+int mgs_debug_set_option(const char* name, int64_t value) {
+    if (name && !strcmp(name, "radix_scanned")) { g_opt_radix_scanned = (int)value; return 0; }
+    if (name && !strcmp(name, "knn_grid_min")) { g_opt_knn_grid_min = value > 0x7FFFFFFF ? 0x7FFFFFFF : (int)value; return 0; }
+    set_error("mgs_debug_set_option: unknown option");
+    return 1;
 }
 
 int mgs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix,

@@ -109,7 +109,8 @@ __global__ void __launch_bounds__(256) duplicate_kernel(int P, const uint2* __re
                                                         uint32_t* vals, int gx, int gy, uint32_t r_cap,
                                                         int32_t* __restrict__ n_touched, uint2* __restrict__ ranges,
                                                         int ntiles, uint32_t* __restrict__ zero_ptr, size_t zero_words,
-                                                        uint32_t* __restrict__ count, uint32_t* __restrict__ overflow) {
+                                                        uint32_t* __restrict__ count, uint32_t* __restrict__ overflow,
+                                                        const uint32_t* __restrict__ depth_err) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     grid_zero(zero_ptr, zero_words);                     // scratch of the tile sort that follows (was its own launch)
@@ -117,8 +118,11 @@ __global__ void __launch_bounds__(256) duplicate_kernel(int P, const uint2* __re
         const uint32_t R = P > 0 ? offsets[P - 1] : 0u;
         count[0] = min(R, r_cap);
         count[1] = R > r_cap ? 1u : 0u;
-        if (overflow) overflow[0] = count[1];
     }
+    // status word of this forward (see MGS_STATUS_* in monogs_raster.h): capacity overflow | depth-sort look-back timeout;
+    // ranges_kernel adds the tile sort's flag
+    if (i == 0 && overflow)
+        overflow[0] = (count ? count[1] : 0u) | ((depth_err && depth_err[0]) ? (uint32_t)MGS_STATUS_DEPTH_SORT_TIMEOUT : 0u);
     if (i < ntiles) ranges[i] = make_uint2(0u, 0u);      // empty-tile default (was a memset)
     if (i < P) n_touched[i] = 0;                         // (was a memset)
     uint32_t idx = 0, nt = 0, off = 0;
@@ -174,6 +178,7 @@ __global__ void __launch_bounds__(256) duplicate_kernel(int P, const uint2* __re
 int launch_duplicate(const mgs_camera& cam, int P, const GeometryState& g, const BinningState& b, uint64_t r_cap,
                      int32_t* n_touched, const ImageState& img, uint64_t sort_n, int sort_bits, uint32_t* count,
                      uint32_t* overflow, hipStream_t s) {
+    const uint32_t* depth_err = P > 0 ? radix_error_flag(g.sort_temp, (uint64_t)P, 32) : nullptr;
     const int ntiles = tiles_x(cam.image_width) * tiles_y(cam.image_height);
     const int n = P > ntiles ? P : ntiles;
     if (n == 0) return 0;
@@ -183,7 +188,7 @@ int launch_duplicate(const mgs_camera& cam, int P, const GeometryState& g, const
     hipLaunchKernelGGL(duplicate_kernel, dim3((n + 255) / 256), dim3(256), 0, s, P, g.rect_sorted, g.perm, g.point_offsets,
                        b.keys_a, b.vals_a, tiles_x(cam.image_width), tiles_y(cam.image_height),
                        (uint32_t)(r_cap > 0xFFFFFFFFull ? 0xFFFFFFFFull : r_cap), n_touched, img.ranges, ntiles, zero_ptr,
-                       zero_words, count, overflow);
+                       zero_words, count, overflow, depth_err);
     MGS_HIP(hipGetLastError());
     return 0;
 }
@@ -209,8 +214,10 @@ int launch_sort(const BinningState& b, uint64_t R, int bits, hipStream_t s, cons
 // tile ranges
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) ranges_kernel(uint64_t R, const uint32_t* __restrict__ n_dev,
-                                                     const uint32_t* __restrict__ keys, uint2* ranges) {
+                                                     const uint32_t* __restrict__ keys, uint2* ranges,
+                                                     const uint32_t* __restrict__ sort_err, uint32_t* __restrict__ status) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0 && status && sort_err[0]) atomicOr(status, (uint32_t)MGS_STATUS_TILE_SORT_TIMEOUT);
     if (n_dev) R = min(R, (uint64_t)n_dev[0]);
     if (i >= R) return;
     const uint32_t t = keys[i];
@@ -226,12 +233,12 @@ __global__ void __launch_bounds__(256) ranges_kernel(uint64_t R, const uint32_t*
     if (i == R - 1) ranges[t].y = (uint32_t)R;
 }
 
-int launch_ranges(const BinningState& b, uint64_t R, const ImageState& img, int ntiles, hipStream_t s,
-                  const uint32_t* n_dev) {
+int launch_ranges(const BinningState& b, uint64_t R, const ImageState& img, int ntiles, int sort_bits, hipStream_t s,
+                  const uint32_t* n_dev, uint32_t* status) {
     (void)ntiles;        // the ranges were zeroed by duplicate_kernel
     if (R == 0) return 0;
     hipLaunchKernelGGL(ranges_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, R, n_dev, b.keys_sorted,
-                       img.ranges);
+                       img.ranges, radix_error_flag(b.sort_temp, R, sort_bits), status);
     MGS_HIP(hipGetLastError());
     return 0;
 }

@@ -191,8 +191,10 @@ int radix_sort_pairs(uint32_t* ka, uint32_t* va, uint32_t* kb, uint32_t* vb, uin
                      const uint2* aux_in = nullptr, uint2* aux_out = nullptr);   // last pass also writes aux_out[i] = aux_in[value i]
 int launch_depth_sort(const GeometryState& g, int P, hipStream_t s);
 int launch_sort(const BinningState& b, uint64_t R, int bits, hipStream_t s, const uint32_t* n_dev = nullptr);
-int launch_ranges(const BinningState& b, uint64_t R, const ImageState& img, int ntiles, hipStream_t s,
-                  const uint32_t* n_dev = nullptr);
+int launch_ranges(const BinningState& b, uint64_t R, const ImageState& img, int ntiles, int sort_bits, hipStream_t s,
+                  const uint32_t* n_dev = nullptr, uint32_t* status = nullptr);
+int set_radix_spin_limit(uint32_t limit);
+extern int g_opt_radix_scanned, g_opt_knn_grid_min;      // test knobs (mgs_debug_set_option)
 int launch_blend_forward(const mgs_camera& cam, const GeometryState& g, const BinningState& b,
                          const ImageState& img, float* out_color, float* out_depth, float* out_opacity,
                          int32_t* n_touched, hipStream_t s);

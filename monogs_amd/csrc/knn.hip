@@ -255,10 +255,8 @@ __global__ void __launch_bounds__(KNN_THREADS) knn_query_kernel(int P, int nb, c
     if (live) out[__float_as_uint(q.w)] = (b0 + b1 + b2) / 3.f;
 }
 
-static int knn_grid_min() {
-    const char* e = getenv("MGS_KNN_GRID_MIN");      // tests force either path at any size
-    return e ? atoi(e) : KNN_GRID_MIN;
-}
+int g_opt_knn_grid_min = -1;         // mgs_debug_set_option("knn_grid_min", n): tests force either path at any size
+static int knn_grid_min() { return g_opt_knn_grid_min >= 0 ? g_opt_knn_grid_min : KNN_GRID_MIN; }
 
 size_t knn_scratch_bytes(int P) {
     if (P < 4) return 256;

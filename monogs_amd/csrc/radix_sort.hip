@@ -29,8 +29,6 @@
 // bounded and raises an error flag instead of hanging.
 #include "common.h"
 
-#include <stdlib.h>
-
 namespace mgs {
 
 constexpr int RS_THREADS = 256;
@@ -50,12 +48,14 @@ constexpr uint64_t RS_FLAG_LOCAL = 1ull << 62;     // count of this tile only
 constexpr uint64_t RS_FLAG_GLOBAL = 2ull << 62;    // inclusive count over tiles 0..this
 constexpr uint64_t RS_COUNT_MASK = (1ull << 62) - 1;
 constexpr uint32_t RS_SPIN_LIMIT = 1u << 22;
+// the bound actually used by the look-back spin: a device word so that a test can shrink it (mgs_debug_set_radix_spin_limit)
+__device__ uint32_t g_rs_spin_limit = RS_SPIN_LIMIT;
 constexpr int RS_WINDOW = 16;                     // predecessor status words fetched per look-back step
 
-// large sorts take the SCANNED path (rs_pass_kernel); MGS_RADIX_SCANNED=0/1 forces one for experiments / tests
+// large sorts take the SCANNED path (rs_pass_kernel); a test knob forces either one (no environment lookups on the launch path)
+int g_opt_radix_scanned = -1;       // mgs_debug_set_option("radix_scanned", -1 | 0 | 1): -1 = by size
 static inline bool rs_scanned(uint64_t n) {
-    const char* e = getenv("MGS_RADIX_SCANNED");
-    if (e && (e[0] == '0' || e[0] == '1')) return e[0] == '1' && rs_items(n) == RS_ITEMS;
+    if (g_opt_radix_scanned >= 0) return g_opt_radix_scanned == 1 && rs_items(n) == RS_ITEMS;
     return rs_items(n) == RS_ITEMS;          // > 1 M pairs: hundreds of tiles
 }
 static inline int rs_passes(int bits) { return (bits + 7) / 8; }
@@ -330,7 +330,7 @@ __global__ void __launch_bounds__(RS_THREADS) rs_pass_kernel(RsPassArgs a) {
                 }
                 j -= used;
                 if (!found && used == 0) {                       // nearest predecessor not published yet
-                    if (++spins > RS_SPIN_LIMIT) {
+                    if (++spins > g_rs_spin_limit) {
                         atomicExch(a.error, 1u);
                         break;
                     }
@@ -433,6 +433,12 @@ int radix_sort_pairs(uint32_t* ka, uint32_t* va, uint32_t* kb, uint32_t* vb, uin
         uint32_t* tv = vin; vin = vout; vout = tv;
     }
     MGS_HIP(hipGetLastError());
+    return 0;
+}
+
+int set_radix_spin_limit(uint32_t limit) {
+    const uint32_t v = limit == 0xFFFFFFFFu ? RS_SPIN_LIMIT : limit;
+    MGS_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_rs_spin_limit), &v, sizeof(v)));
     return 0;
 }
 

@@ -46,7 +46,7 @@ def forward_tables(rs, means3D, opacities, colors_precomp=None, shs=None, scales
         binning = torch.zeros(lib.mgs_binning_bytes(R, W, H), **u8)
         _lib.check(lib.mgs_forward_render(C.byref(cam), P, R, geom.data_ptr(), binning.data_ptr(), img.data_ptr(),
                                           color.data_ptr(), depth.data_ptr(), opacity.data_ptr(),
-                                          n_touched.data_ptr(), None, _stream()), "mgs_forward_render")
+                                          n_touched.data_ptr(), None, None, _stream()), "mgs_forward_render")
         torch.cuda.synchronize()
 
     def view(buf, off, nbytes, dtype):

@@ -1,7 +1,7 @@
 """Fused ``get_loss_mapping`` / ``get_loss_tracking`` (HIP, forward value + analytic gradients).
 
 Same signatures and values as /root/reference/utils/slam_utils.py:58-146 (mirrored in plain PyTorch in
-``monogs_amd.slam_losses`` and checked there against the reference's own outputs); one reduction kernel
+``oracle/slam_losses.py`` -- test infrastructure -- and checked there against the reference's own outputs); one reduction kernel
 per forward and one elementwise kernel per backward instead of ~60 small kernels and two host syncs.
 Differences, both invisible to the rasteriser: the opacity image receives no gradient from the tracking
 loss (the rasteriser ignores dL/dopacity anyway), and ``invert_depth`` is not supported (always False in
@@ -84,7 +84,7 @@ class _FusedLoss(torch.autograd.Function):
 
 def get_loss_mapping(render_image, render_depth, viewpoint, init=False, invert_depth=False, lambda_depth=0.9):
     if invert_depth:
-        raise NotImplementedError("invert_depth is not fused; use monogs_amd.slam_losses.get_loss_mapping")
+        raise NotImplementedError("invert_depth is not supported by the fused loss (always False in the reference's callers)")
     return _FusedLoss.apply(render_image, render_depth, None, viewpoint.exposure_a, viewpoint.exposure_b,
                             viewpoint.rgb, viewpoint.depth, _u8(viewpoint.mask), None, False, bool(init),
                             float(lambda_depth))
@@ -92,7 +92,7 @@ def get_loss_mapping(render_image, render_depth, viewpoint, init=False, invert_d
 
 def get_loss_tracking(render_image, render_depth, render_opacity, viewpoint, invert_depth=False, lambda_depth=0.9):
     if invert_depth:
-        raise NotImplementedError("invert_depth is not fused; use monogs_amd.slam_losses.get_loss_tracking")
+        raise NotImplementedError("invert_depth is not supported by the fused loss (always False in the reference's callers)")
     return _FusedLoss.apply(render_image, render_depth, render_opacity, viewpoint.exposure_a, viewpoint.exposure_b,
                             viewpoint.rgb, viewpoint.depth, _u8(viewpoint.mask), _u8(viewpoint.grad_mask), True,
                             False, 0.9)

@@ -11,8 +11,12 @@ IPC for device tensors -- ``torch.multiprocessing`` shares both the same way) an
 * the writer copies the live map into the buffer that is NOT published (one device-to-device copy per parameter, no
   allocation) and then publishes it by storing ``(sequence, slot, count)`` in the header;
 * a reader takes a consistent snapshot with a seqlock: read the header, take views of ``[:count]`` of that slot, read
-  the header again -- if the sequence moved, retry.  The writer never touches the published slot, so a reader that saw
-  sequence ``s`` can keep using its views until the writer has published twice more (``stale()`` tells).
+  the header again -- if the sequence moved, retry.  The writer never touches the PUBLISHED slot, but with two slots
+  the publish after next re-uses the reader's slot, and it starts copying into it before the header shows the new
+  sequence.  The header therefore carries a write-in-progress word that the writer sets BEFORE the first byte is
+  copied: a reader that took sequence ``s`` may use its views while ``stale(s)`` is False, and must re-check
+  ``stale(s)`` AFTER it has finished reading them (seqlock read side) -- True means the data may be torn: discard
+  and ``acquire()`` again.
 
 Capacity is fixed at creation (MonoGS maps grow by at most a few thousand Gaussians per keyframe; size it for the
 session, 288 GB of HBM is not the constraint).  Works with any set of named tensors, so the activated tensors the tracker
@@ -26,7 +30,7 @@ import torch
 
 
 class MapArena:
-    HEADER = 4           # int64: [sequence, slot, count, reserved]
+    HEADER = 4           # int64: [sequence, slot, count, write in progress (1 + target slot, 0 = none)]
 
     def __init__(self, capacity: int, fields: Dict[str, Sequence[int]], device="cpu", dtype=torch.float32):
         """``fields`` maps a name to the trailing shape of one Gaussian's entry, e.g. {"xyz": (3,), "rotation": (4,)}."""
@@ -57,6 +61,7 @@ class MapArena:
         n = counts.pop()
         if n > self.capacity:
             raise ValueError(f"map has {n} Gaussians, arena capacity is {self.capacity}")
+        self.header[3] = back + 1          # write in progress: readers still holding this slot (sequence seq - 1) are stale NOW
         for k, t in tensors.items():
             self.buffers[k][back][:n].copy_(t.detach().reshape(n, *self.fields[k]))
         dev = next(iter(self.buffers.values()))[0].device
@@ -66,6 +71,7 @@ class MapArena:
         self.header[2] = n
         self.header[1] = back
         self.header[0] = seq + 1
+        self.header[3] = 0
         return seq + 1
 
     # ---- readers (tracker, viewer) --------------------------------------------------------------------------------
@@ -82,5 +88,9 @@ class MapArena:
         raise RuntimeError("MapArena.acquire: the writer kept publishing; no consistent header")
 
     def stale(self, seq: int) -> bool:
-        """True once the writer may be overwriting the slot a reader took at ``seq`` (two publishes later)."""
-        return int(self.header[0]) >= seq + 2
+        """True once the writer may have touched the slot a reader took at ``seq``: the sequence is two ahead, or it is
+        one ahead and a write is in progress (with two slots that write targets the reader's slot).  Check it after
+        reading the views, not only before."""
+        writing = int(self.header[3])       # read before the sequence: a write that completes in between shows as seq + 2
+        cur = int(self.header[0])
+        return cur >= seq + 2 or (cur == seq + 1 and writing != 0)

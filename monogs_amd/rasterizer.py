@@ -53,15 +53,26 @@ def set_sync_free(enabled: bool, headroom: float = 1.5):
     _sync_free["enabled"], _sync_free["headroom"] = bool(enabled), float(headroom)
 
 
+STATUS_CAPACITY_OVERFLOW, STATUS_DEPTH_SORT_TIMEOUT, STATUS_TILE_SORT_TIMEOUT = 1, 2, 4     # MGS_STATUS_* (monogs_raster.h)
+
+
 def check_overflow() -> bool:
-    """True if any capacity-mode forward since the last call dropped instances (synchronises).
-    The capacity hints of the offending shapes are doubled."""
-    hit = False
+    """Reads the status words of the forwards issued since the last call (synchronises).  True if a capacity-mode
+    forward dropped instances -- the capacity hints of the offending shapes are doubled, redo the iteration.  Raises
+    if a radix-sort look-back timed out in any forward (exact or capacity mode): its blend order, hence its images
+    and gradients, are invalid."""
+    hit, sort_fail = False, 0
     for key, flag in _pending_overflow + _graph_overflow:
-        if int(flag.item()) != 0:
+        v = int(flag.item())
+        if v & STATUS_CAPACITY_OVERFLOW:
             hit = True
             _capacity_hint[key] = max(2 * _capacity_hint.get(key, 1), 1024)
+        sort_fail |= v & (STATUS_DEPTH_SORT_TIMEOUT | STATUS_TILE_SORT_TIMEOUT)
     _pending_overflow.clear()
+    if sort_fail:
+        which = [n for b, n in ((STATUS_DEPTH_SORT_TIMEOUT, "depth sort"), (STATUS_TILE_SORT_TIMEOUT, "tile sort")) if sort_fail & b]
+        raise RuntimeError(f"rasteriser: a look-back spin of the {' and the '.join(which)} timed out; "
+                           "the renders since the last check are invalid")
     return hit
 
 
@@ -214,11 +225,18 @@ class _RasterizeGaussians(torch.autograd.Function):
                 R = int(num_rendered.value)
                 _capacity_hint[key] = R
                 binning = torch.empty(lib.mgs_binning_bytes(R, W, H), **u8)
+                status = torch.empty(1, dtype=torch.int32, device=dev) if P > 0 else None   # written by duplicate_kernel
                 _lib.check(lib.mgs_forward_render(
                     C.byref(cam), P, R, geom.data_ptr(), binning.data_ptr(), img.data_ptr(), color.data_ptr(),
-                    depth.data_ptr(), opacity.data_ptr(), n_touched.data_ptr(), tref, _stream()),
+                    depth.data_ptr(), opacity.data_ptr(), n_touched.data_ptr(), _ptr(status), tref, _stream()),
                     "mgs_forward_render")
+                if status is not None:      # (the depth sort's flag was already checked at the count read-back)
+                    _pending_overflow.append((key, status))
+                    if len(_pending_overflow) > 4096:
+                        del _pending_overflow[:2048]
                 ctx.overflow = None
+            if rs.debug:                    # upstream's debug flag: synchronise and check right after the forward
+                check_overflow()
             if timing is not None:
                 d = timing.as_dict()
                 d.update(kind="forward", num_rendered=R, P=P)

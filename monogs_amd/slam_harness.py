@@ -28,7 +28,7 @@ from . import camera as cam
 from .knn import distCUDA2
 from .renderer import render
 from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
-from . import fused_losses, slam_losses
+from . import fused_losses
 from .gaussian_map import GaussianMap
 from .gaussian_optim import activate
 from .pose_optim import PoseAdam
@@ -231,10 +231,13 @@ def make_sequence(n_frames: int, intrinsics="fr3_office", n_gaussians=60000, see
 def run_slam(n_frames=12, intrinsics="fr3_office", tracking_itr_num=100, mapping_itr_num=150, window_size=8,
              kf_interval=4, init_itr_num=300, n_gaussians=60000, device="cuda:0", log=None,
              init_downsample=8, kf_downsample=16, point_size=1.0, fused_losses_on=True, fused_pose_on=True, graph_tracking=False, graph_mapping=False,
-             track_lookahead=1):
+             track_lookahead=1, loss_module=None):
     """Returns a dict with tracking / mapping FPS, iterations and the trajectory error."""
     frames, intr = make_sequence(n_frames, intrinsics, n_gaussians, device=device)
-    L = fused_losses if fused_losses_on else slam_losses
+    if not fused_losses_on and loss_module is None:
+        raise ValueError("fused_losses_on=False needs loss_module= (e.g. the PyTorch mirror oracle/slam_losses.py, "
+                         "which is test infrastructure and not importable from the product package)")
+    L = fused_losses if fused_losses_on else loss_module
     get_loss_mapping, get_loss_tracking = L.get_loss_mapping, L.get_loss_tracking
     bg = torch.zeros(3, device=device)
     gmap = GaussianMap(device, capturable=graph_mapping)

@@ -1,4 +1,6 @@
-"""Photometric / geometric losses on the caller's side of the boundary, as MonoGS computes them.
+"""TEST INFRASTRUCTURE (checker for monogs_amd.fused_losses; the product package does not import it).
+
+Photometric / geometric losses on the caller's side of the boundary, as MonoGS computes them.
 They define the upstream gradients dL/dcolor, dL/ddepth the rasteriser's backward receives.
 
 Mirrors /root/reference/utils/slam_utils.py:58-98 (tracking) and :101-146 (mapping); checked against

@@ -247,6 +247,42 @@ def test_capacity_mode_matches_exact_path(native_lib):
         R._capacity_hint.pop((20000, 640, 480), None)
 
 
+def test_radix_lookback_timeout_is_reported_in_every_mode(native_lib):
+    """The radix sort bounds its inter-workgroup waits; a wait that runs out must surface instead of silently
+    producing a wrong blend order.  With the spin bound forced to 0 (mgs_debug_set_radix_spin_limit) every tile that
+    has to wait at all gives up: the exact path reports the depth sort at its count read-back, the capacity / graph
+    path folds both sorts' flags into the status word that check_overflow() reads."""
+    from monogs_amd import _lib
+    from monogs_amd import rasterizer as R
+    from monogs_amd.rasterizer import GaussianRasterizer
+    lib = _lib.load()
+    sc = make_scene(150000, "fr3_office", seed=77)       # ~150 tiles of 1024 keys in the depth sort: look-back is certain
+    st = _hip_st(sc)
+    dev = lambda t: t.to(DEV)  # noqa: E731
+    args = dict(means3D=dev(sc.means3D), means2D=torch.zeros(150000, 3, device=DEV), opacities=dev(sc.opacities),
+                colors_precomp=dev(sc.colors), scales=dev(sc.scales), rotations=dev(sc.rotations))
+    R.check_overflow()
+    R.set_sync_free(False)
+    ref = GaussianRasterizer(st)(**args)                 # healthy run: records the capacity hint
+    assert not R.check_overflow()
+    try:
+        assert lib.mgs_debug_set_radix_spin_limit(0) == 0
+        with pytest.raises(_lib.MonoGSNativeError, match="look-back"):
+            GaussianRasterizer(st)(**args)               # exact path: depth-sort flag read at the existing sync
+        R._pending_overflow.clear()
+        R.set_sync_free(True)
+        GaussianRasterizer(st)(**args)                   # capacity path: no sync inside ...
+        with pytest.raises(RuntimeError, match="timed out"):
+            R.check_overflow()                           # ... the status word carries the sorts' flags
+    finally:
+        lib.mgs_debug_set_radix_spin_limit(0xFFFFFFFF)
+        R.set_sync_free(False)
+        R._pending_overflow.clear()
+    out = GaussianRasterizer(st)(**args)                 # bound restored: clean again, same image
+    assert not R.check_overflow()
+    assert torch.equal(out[0], ref[0])
+
+
 def test_streams_nograd_and_noncontiguous_inputs(native_lib):
     """The library launches on the caller's current stream, works under no_grad, with inputs that do not
     require grad and with non-contiguous views (made contiguous at the boundary, as upstream's .contiguous())."""
@@ -363,6 +399,56 @@ def test_graph_replay_survives_eager_work_between_replays(native_lib):
         scratch = img.clone()
         scratch.copy_(img)
         (img.double().cumsum(0).to(torch.int16))
+    assert not _r.check_overflow()
+    _r.clear_graph_flags()
+
+
+def test_graph_scratch_is_not_recycled_by_eager_allocations(native_lib):
+    """The lifetime half of the round-1 replay fault: every buffer the captured iteration
+    writes (geometry / binning / image scratch, gradient accumulator, status word, outputs) is allocated DURING capture,
+    i.e. from the graph's private pool, and must stay out of the eager allocator's hands while the graph lives --
+    otherwise the kernel clears that replaced the faulting memset / memcpy nodes would now scribble over live eager
+    tensors silently.  Checked without provoking anything: after capture, a burst of eager allocations of many sizes
+    never lands inside a private-pool segment, before or after replays."""
+    from monogs_amd.rasterizer import GaussianRasterizer
+    from monogs_amd import rasterizer as _r
+    sc = make_scene(6000, "fr3_office", seed=4, device=DEV)
+    rs = _hip_st(sc)
+    m3d = sc.means3D.clone().requires_grad_(True)
+    gc_ = torch.rand(3, rs.image_height, rs.image_width, device=DEV)
+
+    def step():
+        m3d.grad = None
+        out = GaussianRasterizer(rs)(means3D=m3d, means2D=torch.zeros_like(m3d), opacities=sc.opacities,
+                                     colors_precomp=sc.colors, scales=sc.scales, rotations=sc.rotations)
+        (out[0] * gc_).sum().backward()
+        return out[0]
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        step()
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        img = step()
+
+    def private_segments():
+        return [(sg["address"], sg["address"] + sg["total_size"]) for sg in torch.cuda.memory_snapshot()
+                if tuple(sg.get("segment_pool_id", (0, 0))) != (0, 0)]
+
+    segs = private_segments()
+    assert segs, "the capture allocated nothing from a private pool?"
+    inside = lambda t: any(a <= t.data_ptr() < b for a, b in segs)  # noqa: E731
+    assert inside(img) and inside(m3d.grad)            # outputs of the captured iteration live in the graph's pool
+    for round_ in range(3):
+        g.replay()
+        torch.cuda.synchronize()
+        eager = [torch.empty(n, dtype=torch.uint8, device=DEV) for n in (4, 24, 512, 4096, 1 << 16, 1 << 20, 6000 * 64, 1 << 24)]
+        eager += [img.clone(), img.flatten()[:2].cpu().to(DEV)]
+        assert not any(inside(t) for t in eager), round_
+        assert private_segments() == segs              # and the pool itself neither moved nor shrank
+        del eager
     assert not _r.check_overflow()
     _r.clear_graph_flags()
 

@@ -35,7 +35,8 @@ def _grads(loss, xs):
 @pytest.mark.parametrize("H,W", [(24, 32), (480, 640), (237, 325)])
 @pytest.mark.parametrize("init", [False, True])
 def test_fused_mapping_loss(native_lib, H, W, init):
-    from monogs_amd import fused_losses as F, slam_losses as S
+    from monogs_amd import fused_losses as F
+    from oracle import slam_losses as S
     vp, render, rdepth, _ = _vp(H, W, 1, DEV)
     xs = [render, rdepth] + ([] if init else [vp.exposure_a, vp.exposure_b])
     lf = F.get_loss_mapping(render, rdepth, vp, init=init)
@@ -47,7 +48,8 @@ def test_fused_mapping_loss(native_lib, H, W, init):
 
 @pytest.mark.parametrize("H,W", [(24, 32), (480, 640)])
 def test_fused_tracking_loss(native_lib, H, W):
-    from monogs_amd import fused_losses as F, slam_losses as S
+    from monogs_amd import fused_losses as F
+    from oracle import slam_losses as S
     vp, render, rdepth, op = _vp(H, W, 2, DEV)
     xs = [render, rdepth, vp.exposure_a, vp.exposure_b]
     lf = F.get_loss_tracking(render, rdepth, op, vp)

@@ -14,6 +14,12 @@ def _reader(arena, q):
         seq, views = arena.acquire()
         if seq >= 2:
             q.put((seq, int(views["xyz"].shape[0]), float(views["xyz"].sum().item()), str(views["xyz"].device)))
+            # drop every IPC mapping before this process ends (otherwise the producer's allocator warns that a
+            # consumer died holding shared device tensors)
+            del views, arena
+            import gc
+            gc.collect()
+            torch.cuda.ipc_collect()
             return
         time.sleep(0.01)
     q.put(("timeout",))
@@ -31,3 +37,7 @@ def test_device_buffers_across_processes():
     got = q.get(timeout=120)
     p.join(timeout=30)
     assert got == (2, 250, 1500.0, "cuda:0"), got
+    del arena                      # release the exported IPC blocks before this (producer) process goes on
+    import gc
+    gc.collect()
+    torch.cuda.ipc_collect()

@@ -187,9 +187,11 @@ def test_c5_full_size_properties(native_lib, monkeypatch):
     assert torch.equal(t["color"], t2["color"]) and torch.equal(t["point_list"], t2["point_list"])
     assert torch.equal(t["n_touched"], t2["n_touched"])
     # the two radix-sort paths (pre-scanned offsets, the default at this size, and one-sweep look-back) agree bit for bit
-    monkeypatch.setenv("MGS_RADIX_SCANNED", "0")
-    t3 = forward_tables(st, dev(sc.means3D), dev(sc.opacities), **args)
-    monkeypatch.delenv("MGS_RADIX_SCANNED")
+    native_lib.mgs_debug_set_option(b"radix_scanned", 0)
+    try:
+        t3 = forward_tables(st, dev(sc.means3D), dev(sc.opacities), **args)
+    finally:
+        native_lib.mgs_debug_set_option(b"radix_scanned", -1)
     assert torch.equal(t["point_list"], t3["point_list"]) and torch.equal(t["ranges"], t3["ranges"])
     assert torch.equal(t["color"], t3["color"])
     # capacity mode (device-side instance count; what bench.py times) renders the same image as the exact path
@@ -231,13 +233,13 @@ def test_knn_morton_path(native_lib, monkeypatch):
     mixed = torch.cat([sheet, clusters, dup, uniform[:5000], torch.tensor([[1e4, -1e4, 3e3]])])
     for name, pts in (("uniform", uniform), ("mixed", mixed), ("tiny", uniform[:70]), ("same", torch.ones(300, 3))):
         d = pts.to(DEV)
-        monkeypatch.setenv("MGS_KNN_GRID_MIN", "4")               # force the Morton-box path
+        native_lib.mgs_debug_set_option(b"knn_grid_min", 4)            # force the Morton-box path
         grid = distCUDA2(d).cpu()
-        monkeypatch.setenv("MGS_KNN_GRID_MIN", str(1 << 30))      # force the all-pairs sweep
+        native_lib.mgs_debug_set_option(b"knn_grid_min", 1 << 30)      # force the all-pairs sweep
         sweep = distCUDA2(d).cpu()
         assert torch.equal(grid, sweep), (name, (grid - sweep).abs().max())
         assert torch.allclose(grid, dist2_knn(pts), rtol=1e-5, atol=1e-9), name
-    monkeypatch.delenv("MGS_KNN_GRID_MIN")
+    native_lib.mgs_debug_set_option(b"knn_grid_min", -1)
     # full size: 2 M points (the C5 map) in milliseconds; property check = every result is a true 3-NN mean on a sample
     big = (torch.rand(2_000_000, 3, generator=g) * 20 - 10).to(DEV)
     distCUDA2(big)

@@ -33,13 +33,16 @@ def test_graph_tracking_equals_eager_tracking(runs):
     """A captured tracking iteration replayed until the device-side convergence flag rises = the eager loop with its
     per-iteration `if converged: break`.  The blend backward sums with float atomics, so the two runs agree to
     rounding, not bit for bit -- and the exit test (|tau| < 1e-4 on an Adam step that hovers around that size near the
-    optimum) amplifies rounding into a few iterations more or fewer: poses to 2e-5, iteration counts to 15 %."""
+    optimum) amplifies rounding into a few iterations more or fewer, i.e. into pose differences of the size of the exit
+    threshold itself: poses to 2e-4 (camera centres to 0.2 mm), iteration counts to 15 %."""
     eager, graph = runs
     assert graph["ate_rmse_m"] < 2e-3
     for (i, ne), (j, ng) in zip(eager["track_iters_per_frame"], graph["track_iters_per_frame"]):
         assert i == j and abs(ne - ng) <= max(3, 0.15 * ne), (i, ne, ng)
     for (Re, Te), (Rg, Tg) in zip(eager["poses"], graph["poses"]):
-        assert (Re - Rg).abs().max() < 2e-5 and (Te - Tg).abs().max() < 2e-5
+        assert (Re - Rg).abs().max() < 2e-4 and (Te - Tg).abs().max() < 2e-4
+    for ce, cg in zip(eager["camera_centers"], graph["camera_centers"]):
+        assert (ce - cg).norm() < 2e-4
 
 
 def test_mapping_reduces_its_loss(runs):

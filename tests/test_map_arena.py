@@ -73,3 +73,60 @@ def test_two_processes_share_the_buffers():
     p.join(timeout=30)
     assert p.exitcode == 0
     assert results and all(ok for _, ok in results) and results[-1][0] == n
+
+
+def test_reader_holding_views_across_two_publishes_sees_intact_data_or_stale():
+    """A reader that keeps its views while the writer publishes twice more reads either an intact snapshot or gets
+    ``stale() == True`` when it re-checks after reading -- never a torn map that passes for valid.  Every element of a
+    published map equals its sequence number, so a torn read shows up as a non-constant tensor."""
+    import threading
+    n = 400_000
+    a = MapArena(n, {"xyz": (3,), "rotation": (4,)})
+    a.publish({"xyz": torch.full((n, 3), 1.0), "rotation": torch.full((n, 4), 1.0)})
+    stop = threading.Event()
+    published = [1]
+
+    def writer():
+        s = 1
+        while not stop.is_set():
+            s += 1
+            a.publish({"xyz": torch.full((n, 3), float(s)), "rotation": torch.full((n, 4), float(s))})
+            published[0] = s
+
+    t = threading.Thread(target=writer)
+    t.start()
+    torn_but_valid, valid_reads, stale_reads = 0, 0, 0
+    try:
+        import time
+        t_end = time.time() + 3.0
+        while time.time() < t_end:
+            seq, views = a.acquire()
+            time.sleep(0.002)                         # hold the views while the writer keeps publishing
+            lo = min(float(v.min()) for v in views.values())
+            hi = max(float(v.max()) for v in views.values())
+            if a.stale(seq):                          # re-check AFTER reading: the data may be torn, discard it
+                stale_reads += 1
+                continue
+            valid_reads += 1
+            if not (lo == hi == float(seq)):
+                torn_but_valid += 1
+    finally:
+        stop.set()
+        t.join()
+    assert published[0] > 10, "the writer did not race the reader"
+    assert torn_but_valid == 0, (torn_but_valid, valid_reads, stale_reads)
+    assert stale_reads > 0                            # the race really happened
+
+
+def test_stale_is_raised_while_the_readers_slot_is_being_overwritten():
+    """Deterministic version of the race: between 'write in progress' and the header update of the publish after next,
+    ``stale()`` of the reader's sequence is already True (it used to be False for the whole copy)."""
+    a = MapArena(8, {"x": (1,)})
+    a.publish({"x": torch.zeros(8, 1)})
+    seq, _ = a.acquire()
+    a.publish({"x": torch.ones(8, 1)})
+    assert not a.stale(seq)                           # the other slot was written: the reader's slot is intact
+    a.header[3] = (int(a.header[1]) ^ 1) + 1            # what publish() does first: mark the reader's slot as being written
+    assert a.stale(seq)
+    a.header[3] = 0
+    assert not a.stale(seq)

@@ -33,11 +33,16 @@ if __name__ == "__main__":
                     help="with --graph: read the convergence flag of tracking iteration n-1 while n runs")
     a = ap.parse_args()
     from monogs_amd.slam_harness import run_slam
+    loss_module = None
+    if a.torch_losses:          # measurement tool only: the PyTorch mirror lives with the test infrastructure
+        from oracle import slam_losses as loss_module
     cfg = dict(CONFIGS[a.config])
     if a.mapping_iters is not None:
         cfg["mapping_itr_num"] = a.mapping_iters
     out = run_slam(n_frames=a.frames, init_itr_num=a.init_iters, n_gaussians=a.gaussians,
-                   fused_losses_on=not a.torch_losses, fused_pose_on=not a.torch_pose, graph_tracking=a.graph, graph_mapping=a.graph and not a.eager_mapping, track_lookahead=a.lookahead,
+                   fused_losses_on=not a.torch_losses, fused_pose_on=not a.torch_pose, graph_tracking=a.graph, graph_mapping=a.graph and not a.eager_mapping, track_lookahead=a.lookahead, loss_module=loss_module,
                    log=lambda s: print("[slam]", s, file=sys.stderr, flush=True), **cfg)
     out["workload"] = f"synthetic {a.config}-like sequence, {a.frames} frames"
+    for k in ("poses", "camera_centers", "camera_centers_gt"):      # tensors: not JSON
+        out.pop(k, None)
     print(json.dumps(out))

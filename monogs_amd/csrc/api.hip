@@ -166,12 +166,12 @@ int mgs_forward_preprocess(const mgs_camera* cam, int32_t P, const float* means3
     if (int rc = launch_scan(g, P, s)) return rc;
     tm.mark();
     if (num_rendered) {
-        uint32_t total = 0, sort_error = 0;
+        uint32_t total = 0, sort_errors[RADIX_ERROR_WORDS] = {0, 0, 0, 0};
         MGS_HIP(hipMemcpyAsync(&total, g.point_offsets + (P - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        MGS_HIP(hipMemcpyAsync(&sort_error, radix_error_flag(g.sort_temp, (uint64_t)P, 32), sizeof(uint32_t),
+        MGS_HIP(hipMemcpyAsync(sort_errors, radix_error_flag(g.sort_temp, (uint64_t)P, 32), sizeof(sort_errors),
                                hipMemcpyDeviceToHost, s));
         MGS_HIP(hipStreamSynchronize(s));
-        if (sort_error) { set_error("depth sort: a look-back spin timed out (results invalid)"); return 3; }
+        if (sort_errors[0] | sort_errors[1] | sort_errors[2] | sort_errors[3]) { set_error("depth sort: a look-back spin timed out (results invalid)"); return 3; }
         *num_rendered = total;
     }
     if (timing) {

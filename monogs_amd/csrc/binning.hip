@@ -114,15 +114,18 @@ __global__ void __launch_bounds__(256) duplicate_kernel(int P, const uint2* __re
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     grid_zero(zero_ptr, zero_words);                     // scratch of the tile sort that follows (was its own launch)
+    // a depth sort whose look-back timed out left perm / rect_sorted / offsets partly unwritten: emit nothing (the live
+    // count is published as 0, so the tile sort, the ranges and the blend kernels have nothing to do either)
+    const bool depth_bad = depth_err && radix_failed(depth_err) != 0u;
     if (i == 0 && count) {                               // capacity mode: live instance count + overflow flag (was a launch)
-        const uint32_t R = P > 0 ? offsets[P - 1] : 0u;
+        const uint32_t R = (P > 0 && !depth_bad) ? offsets[P - 1] : 0u;
         count[0] = min(R, r_cap);
         count[1] = R > r_cap ? 1u : 0u;
     }
     // status word of this forward (see MGS_STATUS_* in monogs_raster.h): capacity overflow | depth-sort look-back timeout;
     // ranges_kernel adds the tile sort's flag
     if (i == 0 && overflow)
-        overflow[0] = (count ? count[1] : 0u) | ((depth_err && depth_err[0]) ? (uint32_t)MGS_STATUS_DEPTH_SORT_TIMEOUT : 0u);
+        overflow[0] = (count ? count[1] : 0u) | (depth_bad ? (uint32_t)MGS_STATUS_DEPTH_SORT_TIMEOUT : 0u);
     if (i < ntiles) ranges[i] = make_uint2(0u, 0u);      // empty-tile default (was a memset)
     if (i < P) n_touched[i] = 0;                         // (was a memset)
     uint32_t idx = 0, nt = 0, off = 0;
@@ -134,6 +137,7 @@ __global__ void __launch_bounds__(256) duplicate_kernel(int P, const uint2* __re
         nt = (uint32_t)(w * h);
         x0 = (int)(r.x & 0xFFFFu); y0 = (int)(r.x >> 16); x1 = x0 + w;
     }
+    if (depth_bad) nt = 0;                               // (wave-uniform, grid-uniform)
     if (nt) off = i == 0 ? 0u : offsets[i - 1];
     // Load-balanced emission.  The 64 Gaussians of the wave own the consecutive output slots [S, E); the wave walks
     // that range 64 slots at a time (aligned, so every store is one coalesced 256-byte line) and each lane finds the
@@ -217,7 +221,10 @@ __global__ void __launch_bounds__(256) ranges_kernel(uint64_t R, const uint32_t*
                                                      const uint32_t* __restrict__ keys, uint2* ranges,
                                                      const uint32_t* __restrict__ sort_err, uint32_t* __restrict__ status) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0 && status && sort_err[0]) atomicOr(status, (uint32_t)MGS_STATUS_TILE_SORT_TIMEOUT);
+    // a tile sort whose look-back timed out: keys[] is partly unwritten (arbitrary tile ids): leave every range empty
+    const bool sort_bad = radix_failed(sort_err) != 0u;
+    if (i == 0 && status && sort_bad) atomicOr(status, (uint32_t)MGS_STATUS_TILE_SORT_TIMEOUT);
+    if (sort_bad) return;
     if (n_dev) R = min(R, (uint64_t)n_dev[0]);
     if (i >= R) return;
     const uint32_t t = keys[i];

@@ -184,7 +184,9 @@ int launch_duplicate(const mgs_camera& cam, int P, const GeometryState& g, const
 size_t sort_temp_bytes(uint64_t n, int bits);
 size_t radix_temp_bytes(uint64_t n, int bits);
 bool radix_result_in_b(int bits);
+constexpr int RADIX_ERROR_WORDS = 4;      // = RS_MAX_PASSES (radix_sort.hip)
 const uint32_t* radix_error_flag(void* temp, uint64_t n, int bits);
+__device__ __forceinline__ uint32_t radix_failed(const uint32_t* __restrict__ e) { return (e[0] | e[1]) | (e[2] | e[3]); }
 void radix_zero_region(void* temp, uint64_t n, int bits, uint32_t** ptr, size_t* words);   // what must be 0 before a sort
 int radix_sort_pairs(uint32_t* ka, uint32_t* va, uint32_t* kb, uint32_t* vb, uint64_t n, int bits, void* temp,
                      hipStream_t s, const uint32_t* n_dev = nullptr, bool temp_zeroed = false,

@@ -65,7 +65,7 @@ static inline uint32_t rs_tiles(uint64_t n) {
 }
 
 // temp layout: [hist: RS_MAX_PASSES*256 u32][base: RS_MAX_PASSES*256 u32][tickets: RS_MAX_PASSES u32]
-//              [error: 1 u32][pad][status: passes * tiles * 256 u64]
+//              [error: RS_MAX_PASSES u32][pad][status: passes * tiles * 256 u64]
 struct RsTemp {
     uint32_t* hist;
     uint32_t* base;
@@ -80,8 +80,8 @@ static RsTemp rs_carve(void* temp, uint64_t n, int bits) {
     t.hist = (uint32_t*)p;
     t.base = t.hist + RS_MAX_PASSES * RS_RADIX;
     t.tickets = t.base + RS_MAX_PASSES * RS_RADIX;
-    t.error = t.tickets + RS_MAX_PASSES;
-    char* q = (char*)align_up((size_t)(t.error + 1), 256);
+    t.error = t.tickets + RS_MAX_PASSES;      // one word per pass
+    char* q = (char*)align_up((size_t)(t.error + RS_MAX_PASSES), 256);
     t.status = (uint64_t*)q;
     const size_t status_bytes = (size_t)rs_passes(bits) * rs_tiles(n) * RS_RADIX * sizeof(uint64_t);
     t.zero_bytes = (size_t)(q - p) + status_bytes;
@@ -194,7 +194,8 @@ struct RsPassArgs {
     const uint32_t* hist;     // [256] global count of each digit for this pass
     uint64_t* status;         // [tiles][256]
     uint32_t* ticket;
-    uint32_t* error;
+    uint32_t* error;          // [RS_MAX_PASSES] one word per pass: pass p raises error[p] when a look-back spin times out
+    int pass;
     const uint2* aux_in;      // optional (last pass): aux_out[final position] = aux_in[value]
     uint2* aux_out;
     const uint32_t* scanned;  // SCANNED path: [256][tiles] exclusive scan (digit-major) of the per-tile digit counts
@@ -219,6 +220,15 @@ __global__ void __launch_bounds__(RS_THREADS) rs_pass_kernel(RsPassArgs a) {
     __shared__ uint32_t s_tile;
 
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    if (!SCANNED) {
+        // A timed-out look-back in an EARLIER pass left part of this pass's input unwritten: ranking it against the
+        // histogram of the original keys could place pairs past the end of the buffers.  Such a pass does nothing (the
+        // words of earlier passes cannot change while this one runs, so every tile takes the same decision), and the
+        // consumers of the sort treat a raised flag as "no output" (duplicate_kernel, ranges_kernel).
+        uint32_t failed = 0;
+        for (int q = 0; q < a.pass; ++q) failed |= a.error[q];
+        if (failed) return;
+    }
     if (t == 0) s_tile = (!SCANNED && a.ticket) ? atomicAdd(a.ticket, 1u) : blockIdx.x;   // a returning atomic is a ~2 us round trip
     for (int i = t; i < RS_WAVES * RS_RADIX; i += RS_THREADS) (&wave_hist[0][0])[i] = 0;
     __syncthreads();
@@ -331,7 +341,7 @@ __global__ void __launch_bounds__(RS_THREADS) rs_pass_kernel(RsPassArgs a) {
                 j -= used;
                 if (!found && used == 0) {                       // nearest predecessor not published yet
                     if (++spins > g_rs_spin_limit) {
-                        atomicExch(a.error, 1u);
+                        atomicExch(a.error + a.pass, 1u);
                         break;
                     }
                     __builtin_amdgcn_s_sleep(1);
@@ -377,7 +387,8 @@ __global__ void __launch_bounds__(RS_THREADS) rs_pass_kernel(RsPassArgs a) {
 // (ka, va) when it is even (radix_result_in_b tells which).
 bool radix_result_in_b(int bits) { return (rs_passes(bits) & 1) != 0; }
 
-// device word that a timed-out look-back spin sets to 1 (checked by the caller at its next sync point)
+// RADIX_ERROR_WORDS device words (one per pass) that a timed-out look-back spin sets to 1; any non-zero word = the
+// sort's output is invalid (checked by the kernels that consume it and by the caller at its next sync point)
 const uint32_t* radix_error_flag(void* temp, uint64_t n, int bits) { return rs_carve(temp, n ? n : 1, bits).error; }
 
 // The region of `temp` that must be zero when the sort starts (histograms, tickets, error flag, status words); a
@@ -413,6 +424,7 @@ int radix_sort_pairs(uint32_t* ka, uint32_t* va, uint32_t* kb, uint32_t* vb, uin
         // <= one workgroup per CU: the whole grid is co-resident whatever the dispatch order, so block ids are safe
         a.ticket = tiles <= 256u ? nullptr : t.tickets + p;
         a.error = t.error;
+        a.pass = p;
         a.scanned = counts; a.tiles = tiles;
         const bool last = p == npasses - 1;
         a.aux_in = last ? aux_in : nullptr; a.aux_out = last ? aux_out : nullptr;

@@ -27,7 +27,6 @@ GeometryState GeometryState::carve(void* base, int P) {
     char* p = (char*)align_up((size_t)base, 256);
     GeometryState g;
     g.rec = (float*)take(p, (size_t)P * REC_FLOATS * sizeof(float));
-    g.tiles_touched = (uint32_t*)take(p, (size_t)P * sizeof(uint32_t));
     g.depth_key = (uint32_t*)take(p, (size_t)P * sizeof(uint32_t));
     g.depth_alt = (uint32_t*)take(p, (size_t)P * sizeof(uint32_t));
     g.iota = (uint32_t*)take(p, (size_t)P * sizeof(uint32_t));

@@ -111,9 +111,12 @@ __global__ void __launch_bounds__(256) duplicate_kernel(int P, const uint2* __re
                                                         int ntiles, uint32_t* __restrict__ zero_ptr, size_t zero_words,
                                                         uint32_t* __restrict__ count, uint32_t* __restrict__ overflow,
                                                         const uint32_t* __restrict__ depth_err) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.x * 256 + threadIdx.x;          // (launched with 256 threads; blockDim would be a packet fetch)
     const int lane = threadIdx.x & 63;
-    grid_zero(zero_ptr, zero_words);                     // scratch of the tile sort that follows (was its own launch)
+    {   // scratch of the tile sort that follows (was its own launch); the launch has max(P, ntiles) threads, rounded up
+        const int n_thr = P > ntiles ? P : ntiles;
+        grid_zero(zero_ptr, zero_words, (size_t)((n_thr + 255) / 256) * 256, 256);
+    }
     // a depth sort whose look-back timed out left perm / rect_sorted / offsets partly unwritten: emit nothing (the live
     // count is published as 0, so the tile sort, the ranges and the blend kernels have nothing to do either)
     const bool depth_bad = depth_err && radix_failed(depth_err) != 0u;
@@ -220,7 +223,7 @@ int launch_sort(const BinningState& b, uint64_t R, int bits, hipStream_t s, cons
 __global__ void __launch_bounds__(256) ranges_kernel(uint64_t R, const uint32_t* __restrict__ n_dev,
                                                      const uint32_t* __restrict__ keys, uint2* ranges,
                                                      const uint32_t* __restrict__ sort_err, uint32_t* __restrict__ status) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     // a tile sort whose look-back timed out: keys[] is partly unwritten (arbitrary tile ids): leave every range empty
     const bool sort_bad = radix_failed(sort_err) != 0u;
     if (i == 0 && status && sort_bad) atomicOr(status, (uint32_t)MGS_STATUS_TILE_SORT_TIMEOUT);

@@ -40,6 +40,20 @@ enum : int {
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// Wave-uniform read-only inputs (camera matrices, background colour): read through the CONSTANT address space, so the
+// backend always selects scalar loads (s_load_dwordx8/x16, all issued at once) for them.  Through a generic pointer
+// it falls back to per-lane vector loads with a vmcnt(0) wait after each group as soon as the kernel also stores to
+// global memory (its no-clobber analysis gives up): the per-Gaussian kernels spent seven dependent memory round trips
+// on their 51 camera floats that way.  Valid because these buffers are written by an EARLIER kernel, never by the one
+// reading them (kernel boundaries invalidate the scalar cache).
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const float __attribute__((address_space(4))) * const_float_p;
+#define MGS_CONST(p) ((mgs::const_float_p)(p))
+#else
+typedef const float* const_float_p;
+#define MGS_CONST(p) (p)
+#endif
+
 // ---- 64-lane inclusive scan (u32 add) on the DPP data path: 4 row shifts + 2 row broadcasts, ~60 cycles, instead of
 // six __shfl_up round trips through ds_bpermute (the LDS crossbar, >100 cycles each).
 __device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t v) {
@@ -71,8 +85,10 @@ __global__ static void zero_fill_kernel(uint32_t* __restrict__ p, size_t n_words
     }
 }
 // the same clear, done by the threads of a kernel that runs anyway (p 16-byte aligned): saves a launch
-__device__ __forceinline__ void grid_zero(uint32_t* __restrict__ p, size_t n_words) {
-    const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+// (`threads` = total threads of the launch, passed by the host: blockDim / gridDim would be fetched from the dispatch
+//  packet with a vector load + wait, a memory round trip at the very start of the kernel)
+__device__ __forceinline__ void grid_zero(uint32_t* __restrict__ p, size_t n_words, size_t threads, int block) {
+    const size_t i0 = (size_t)blockIdx.x * block + threadIdx.x, stride = threads;
     uint4* q = reinterpret_cast<uint4*>(p);
     const size_t nv = n_words / 4;
     for (size_t i = i0; i < nv; i += stride) q[i] = make_uint4(0u, 0u, 0u, 0u);
@@ -80,7 +96,7 @@ __device__ __forceinline__ void grid_zero(uint32_t* __restrict__ p, size_t n_wor
 }
 // two regions in one launch (the second one small): gradient accumulator + the 6 pose-gradient floats
 __global__ static void zero_fill2_kernel(uint32_t* __restrict__ p, size_t n_words, uint32_t* __restrict__ p2, int n2) {
-    grid_zero(p, n_words);
+    grid_zero(p, n_words, (size_t)gridDim.x * 256, 256);
     if (blockIdx.x == 0 && (int)threadIdx.x < n2) p2[threadIdx.x] = 0u;
 }
 static inline hipError_t zero_fill2(void* ptr, size_t bytes, void* ptr2, size_t bytes2, hipStream_t s) {
@@ -105,13 +121,12 @@ static inline hipError_t zero_fill(void* ptr, size_t bytes, hipStream_t s) {
 // ---- scratch carving (every sub-buffer 256-byte aligned) ---------------------------------
 struct GeometryState {
     float* rec;               // [P][16]
-    uint32_t* tiles_touched;  // [P]
     uint32_t* depth_key;      // [P] float32 bits of the view-space depth (0xFFFFFFFF when culled); sort input
     uint32_t* depth_alt;      // [P] ping-pong partner of depth_key
     uint32_t* iota;           // [P] 0..P-1; sort input
     uint32_t* iota_alt;       // [P] ping-pong partner of iota
     uint32_t* perm;           // = iota or iota_alt: Gaussian index in (depth, index) order -- culled ones last
-    uint32_t* point_offsets;  // [P] inclusive scan of tiles_touched[perm[i]]
+    uint32_t* point_offsets;  // [P] inclusive scan, in depth order, of the tiles each Gaussian touches (w * h of its rectangle)
     uint32_t* scan_blocks;    // [scan_nblocks(P) + 64]
     uint8_t* clamped;         // [P][4] SH colour clamp flags
     uint2* rect;              // [P] tile rectangle {x0 | y0 << 16, w | h << 16} (w = h = 0: culled), by Gaussian index

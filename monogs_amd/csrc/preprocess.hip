@@ -36,11 +36,33 @@ struct Cam {
     int W, H, gx, gy, deg, M;
 };
 
-__device__ __forceinline__ void load_cam(Cam& c, const float* V, const float* PM, const float* PR,
-                                         const float* campos) {
+__device__ __forceinline__ void load_cam(Cam& c, const float* V_, const float* PM_, const float* PR_,
+                                         const float* campos_) {
+    const const_float_p V = MGS_CONST(V_), PM = MGS_CONST(PM_), PR = MGS_CONST(PR_), campos = MGS_CONST(campos_);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { c.V[i] = V[i]; c.PM[i] = PM[i]; c.PR[i] = PR ? PR[i] : 0.f; }
+    for (int i = 0; i < 16; ++i) { c.V[i] = V[i]; c.PM[i] = PM[i]; }
+    if (PR_) {                   // (wave-uniform; the forward does not need the raw projection)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) c.PR[i] = PR[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) c.PR[i] = 0.f;
+    }
     c.campos[0] = campos[0]; c.campos[1] = campos[1]; c.campos[2] = campos[2];
+}
+
+// An empty asm that "uses" the camera block: pins its scalar loads in front of the arithmetic (the compiler otherwise
+// sinks each group to its first use, i.e. behind the per-lane loads' wait: a second, dependent round trip).
+__device__ __forceinline__ void pin_cam(const Cam& c, bool with_pr) {
+    asm volatile("" ::"s"(c.V[0]), "s"(c.V[1]), "s"(c.V[2]), "s"(c.V[3]), "s"(c.V[4]), "s"(c.V[5]), "s"(c.V[6]), "s"(c.V[7]),
+                 "s"(c.V[8]), "s"(c.V[9]), "s"(c.V[10]), "s"(c.V[11]), "s"(c.V[12]), "s"(c.V[13]), "s"(c.V[14]), "s"(c.V[15]));
+    asm volatile("" ::"s"(c.PM[0]), "s"(c.PM[1]), "s"(c.PM[2]), "s"(c.PM[3]), "s"(c.PM[4]), "s"(c.PM[5]), "s"(c.PM[6]),
+                 "s"(c.PM[7]), "s"(c.PM[8]), "s"(c.PM[9]), "s"(c.PM[10]), "s"(c.PM[11]), "s"(c.PM[12]), "s"(c.PM[13]),
+                 "s"(c.PM[14]), "s"(c.PM[15]), "s"(c.campos[0]), "s"(c.campos[1]), "s"(c.campos[2]));
+    if (with_pr)
+        asm volatile("" ::"s"(c.PR[0]), "s"(c.PR[1]), "s"(c.PR[2]), "s"(c.PR[3]), "s"(c.PR[4]), "s"(c.PR[5]), "s"(c.PR[6]),
+                     "s"(c.PR[7]), "s"(c.PR[8]), "s"(c.PR[9]), "s"(c.PR[10]), "s"(c.PR[11]), "s"(c.PR[12]), "s"(c.PR[13]),
+                     "s"(c.PR[14]), "s"(c.PR[15]));
 }
 
 __device__ __forceinline__ void cov3d_from_scale_rot(const float s[3], const float q[4], float mod, float cov[6],
@@ -141,7 +163,6 @@ struct PreArgs {
     const float *means3D, *shs, *colors, *opacities, *scales, *rotations, *cov3D;
     const float *V, *PM, *campos;
     float* rec;
-    uint32_t* tiles_touched;
     uint32_t* depth_key;
     uint32_t* iota;
     uint8_t* clamped;
@@ -150,29 +171,37 @@ struct PreArgs {
     float tanfovx, tanfovy, focal_x, focal_y, mod;
     int P, W, H, gx, gy, deg, M;
     int iso;                  // scales holds ONE float per Gaussian
+    int rot_aligned16;        // rotations may be read with 16-byte loads
     uint32_t* zero_ptr;       // scratch of the depth sort that follows: cleared here instead of by its own launch
     size_t zero_words;
 };
 
-__global__ void __launch_bounds__(256) preprocess_forward_kernel(PreArgs a) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    grid_zero(a.zero_ptr, a.zero_words);
-    if (idx >= a.P) return;
-    a.radii[idx] = 0;
-    a.tiles_touched[idx] = 0;
-    a.rect[idx] = make_uint2(0u, 0u);
-    a.depth_key[idx] = 0xFFFFFFFFu;       // culled Gaussians sort behind every visible one
-    a.iota[idx] = (uint32_t)idx;
+// 16-byte per-lane loads where the caller's tensor allows it (torch allocations are 256-byte aligned; a sliced view may not be)
+__device__ __forceinline__ void load4(const float* __restrict__ p, bool aligned16, float o[4]) {
+    if (aligned16) {
+        const float4 v = *reinterpret_cast<const float4*>(p);
+        o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+    } else {
+        o[0] = p[0]; o[1] = p[1]; o[2] = p[2]; o[3] = p[3];
+    }
+}
 
-    Cam c;
-    load_cam(c, a.V, a.PM, nullptr, a.campos);
-    c.tanfovx = a.tanfovx; c.tanfovy = a.tanfovy; c.focal_x = a.focal_x; c.focal_y = a.focal_y;
+struct PreOut {
+    float4 r0, r1, r2, r3;     // the 64-byte blend record
+    int radius;
+    uint2 rect;
+    uint32_t key;
+};
 
-    const float x = a.means3D[3 * idx], y = a.means3D[3 * idx + 1], z = a.means3D[3 * idx + 2];
+// One Gaussian, inputs already in registers.  false = culled (near plane, degenerate covariance, off screen).
+template <bool COV, bool PRECOMP>
+__device__ __forceinline__ bool preprocess_one(const PreArgs& a, const Cam& c, int idx, float x, float y, float z,
+                                               const float cov_in[6], const float s[3], const float q[4],
+                                               const float col_in[3], float opac, PreOut& o) {
     float pv[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) pv[k] = dot3p(c.V[k], c.V[4 + k], c.V[8 + k], c.V[12 + k], x, y, z);
-    if (!(pv[2] > 0.2f)) return;                          // near cull (also rejects NaN)
+    if (!(pv[2] > 0.2f)) return false;                    // near cull (also rejects NaN)
     float ph[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) ph[k] = dot3p(c.PM[k], c.PM[4 + k], c.PM[8 + k], c.PM[12 + k], x, y, z);
@@ -180,21 +209,17 @@ __global__ void __launch_bounds__(256) preprocess_forward_kernel(PreArgs a) {
     const float projx = ph[0] * p_w, projy = ph[1] * p_w;
 
     float cov[6];
-    if (a.cov3D) {
+    if (COV) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) cov[k] = a.cov3D[6 * idx + k];
+        for (int k = 0; k < 6; ++k) cov[k] = cov_in[k];
     } else {
-        const float s0 = a.iso ? a.scales[idx] : a.scales[3 * idx];
-        const float s[3] = {s0, a.iso ? s0 : a.scales[3 * idx + 1], a.iso ? s0 : a.scales[3 * idx + 2]};
-        const float q[4] = {a.rotations[4 * idx], a.rotations[4 * idx + 1], a.rotations[4 * idx + 2],
-                            a.rotations[4 * idx + 3]};
         float Mm[9];
         cov3d_from_scale_rot(s, q, a.mod, cov, Mm);
     }
     Proj p;
     project_cov(c, pv, cov, p);
     const float det = p.cxx * p.cyy - p.cxy * p.cxy;
-    if (det == 0.0f) return;
+    if (det == 0.0f) return false;
     const float det_inv = 1.f / det;
     const float ca = p.cyy * det_inv, cb = -p.cxy * det_inv, cc = p.cxx * det_inv;
     const float mid = 0.5f * (p.cxx + p.cyy);
@@ -203,15 +228,15 @@ __global__ void __launch_bounds__(256) preprocess_forward_kernel(PreArgs a) {
     const float radius = ceilf(3.f * sqrtf(lam));
     const float px = ((projx + 1.0f) * (float)a.W - 1.0f) * 0.5f;
     const float py = ((projy + 1.0f) * (float)a.H - 1.0f) * 0.5f;
-    if (!(isfinite(px) && isfinite(py) && isfinite(radius))) return;
+    if (!(isfinite(px) && isfinite(py) && isfinite(radius))) return false;
     int x0, y0, x1, y1;
     tile_rect(px, py, radius, a.gx, a.gy, x0, y0, x1, y1);
     const int ntile = (x1 - x0) * (y1 - y0);
-    if (ntile == 0) return;
+    if (ntile == 0) return false;
 
     float rgb[3];
-    if (a.colors) {
-        rgb[0] = a.colors[3 * idx]; rgb[1] = a.colors[3 * idx + 1]; rgb[2] = a.colors[3 * idx + 2];
+    if (PRECOMP) {
+        rgb[0] = col_in[0]; rgb[1] = col_in[1]; rgb[2] = col_in[2];
     } else {
         float d[3] = {x - c.campos[0], y - c.campos[1], z - c.campos[2]};
         const float len = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
@@ -224,7 +249,6 @@ __global__ void __launch_bounds__(256) preprocess_forward_kernel(PreArgs a) {
         }
     }
 
-    const float opac = a.opacities[idx];
     // Half extents of the axis-aligned box around the alpha >= 1/255 ellipse, padded: the blend
     // kernels skip an instance for a whole 8x8 quadrant when the box misses the quadrant, which
     // cannot change any pixel because every skipped pair has alpha < 1/255.
@@ -240,17 +264,64 @@ __global__ void __launch_bounds__(256) preprocess_forward_kernel(PreArgs a) {
         ex = ey = 3.0e38f;
     }
 
-    float4* rec = reinterpret_cast<float4*>(a.rec + (size_t)idx * REC_FLOATS);
-    rec[0] = make_float4(px, py, ex, ey);
+    o.r0 = make_float4(px, py, ex, ey);
     // conic pre-scaled for the blend kernels: alpha = opacity * exp2(ka dx^2 + kc dy^2 + kb dx dy)
     constexpr float LOG2E = 1.4426950408889634f;
-    rec[1] = make_float4(-0.5f * LOG2E * ca, -LOG2E * cb, -0.5f * LOG2E * cc, opac);
-    rec[2] = make_float4(rgb[0], rgb[1], rgb[2], pv[2]);
-    rec[3] = make_float4(na, nb, nc, radius);
-    a.radii[idx] = (int)radius;
-    a.tiles_touched[idx] = (uint32_t)ntile;
-    a.rect[idx] = make_uint2((uint32_t)x0 | ((uint32_t)y0 << 16), (uint32_t)(x1 - x0) | ((uint32_t)(y1 - y0) << 16));
-    a.depth_key[idx] = __float_as_uint(pv[2]);   // > 0.2, so the bit pattern orders like the value
+    o.r1 = make_float4(-0.5f * LOG2E * ca, -LOG2E * cb, -0.5f * LOG2E * cc, opac);
+    o.r2 = make_float4(rgb[0], rgb[1], rgb[2], pv[2]);
+    o.r3 = make_float4(na, nb, nc, radius);
+    o.radius = (int)radius;
+    o.rect = make_uint2((uint32_t)x0 | ((uint32_t)y0 << 16), (uint32_t)(x1 - x0) | ((uint32_t)(y1 - y0) << 16));
+    o.key = __float_as_uint(pv[2]);            // > 0.2, so the bit pattern orders like the value
+    return true;
+}
+
+// COV: the 3-D covariance is given (else scales + rotations).  PRECOMP: colours are given (else spherical harmonics).
+// Compile-time, so that the input loads below form one branch-free group.
+template <bool COV, bool PRECOMP>
+__global__ void __launch_bounds__(256) preprocess_forward_kernel(PreArgs a) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;        // (launched with 256 threads; blockDim would be a packet fetch)
+    grid_zero(a.zero_ptr, a.zero_words, (size_t)((a.P + 255) / 256) * 256, 256);
+    if (idx >= a.P) return;
+    // ---- every per-Gaussian input is requested up front: ONE memory round trip before the arithmetic starts (a load
+    //      placed behind each early exit used to cost a dependent round trip of its own; the 32 bytes this reads for a
+    //      Gaussian that turns out to be culled are cheaper than the latency they hide)
+    Cam c;
+    load_cam(c, a.V, a.PM, nullptr, a.campos);
+    c.tanfovx = a.tanfovx; c.tanfovy = a.tanfovy; c.focal_x = a.focal_x; c.focal_y = a.focal_y;
+    const float x = a.means3D[3 * idx], y = a.means3D[3 * idx + 1], z = a.means3D[3 * idx + 2];
+    const float opac = a.opacities[idx];
+    float cov_in[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, s[3] = {0.f, 0.f, 0.f}, q[4] = {1.f, 0.f, 0.f, 0.f};
+    float col_in[3] = {0.f, 0.f, 0.f};
+    if (COV) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) cov_in[k] = a.cov3D[6 * idx + k];
+    } else {
+        // isotropic maps hold ONE scale per Gaussian: the same address three times, no branch
+        const float* sp = a.scales + (a.iso ? (size_t)idx : 3 * (size_t)idx);
+        const int o1 = a.iso ? 0 : 1, o2 = a.iso ? 0 : 2;
+        s[0] = sp[0]; s[1] = sp[o1]; s[2] = sp[o2];
+        load4(a.rotations + 4 * (size_t)idx, a.rot_aligned16 != 0, q);
+    }
+    if (PRECOMP) { col_in[0] = a.colors[3 * idx]; col_in[1] = a.colors[3 * idx + 1]; col_in[2] = a.colors[3 * idx + 2]; }
+    // (an empty asm that "uses" every loaded value: the compiler otherwise sinks each load to its first use, behind the
+    //  early exits, and the kernel pays one dependent memory round trip per group again)
+    asm volatile("" ::"v"(x), "v"(y), "v"(z), "v"(opac), "v"(s[0]), "v"(s[1]), "v"(s[2]), "v"(q[0]), "v"(q[1]), "v"(q[2]),
+                 "v"(q[3]), "v"(col_in[0]), "v"(col_in[1]), "v"(col_in[2]));
+    if (COV) asm volatile("" ::"v"(cov_in[0]), "v"(cov_in[1]), "v"(cov_in[2]), "v"(cov_in[3]), "v"(cov_in[4]), "v"(cov_in[5]));
+    pin_cam(c, false);
+
+    PreOut o;
+    const bool vis = preprocess_one<COV, PRECOMP>(a, c, idx, x, y, z, cov_in, s, q, col_in, opac, o);
+    // ---- every output written once (culled Gaussians: radius 0, empty rectangle, key behind every visible one)
+    a.radii[idx] = vis ? o.radius : 0;
+    a.rect[idx] = vis ? o.rect : make_uint2(0u, 0u);
+    a.depth_key[idx] = vis ? o.key : 0xFFFFFFFFu;
+    a.iota[idx] = (uint32_t)idx;
+    if (vis) {
+        float4* rec = reinterpret_cast<float4*>(a.rec + (size_t)idx * REC_FLOATS);
+        rec[0] = o.r0; rec[1] = o.r1; rec[2] = o.r2; rec[3] = o.r3;
+    }
 }
 
 int launch_preprocess_forward(const mgs_camera& cam, int P, const float* means3D, const float* shs,
@@ -261,7 +332,8 @@ int launch_preprocess_forward(const mgs_camera& cam, int P, const float* means3D
     a.means3D = means3D; a.shs = shs; a.colors = colors_precomp; a.opacities = opacities;
     a.scales = scales; a.rotations = rotations; a.cov3D = cov3D_precomp;
     a.V = cam.viewmatrix; a.PM = cam.projmatrix; a.campos = cam.campos;
-    a.rec = g.rec; a.tiles_touched = g.tiles_touched; a.depth_key = g.depth_key; a.iota = g.iota;
+    a.rec = g.rec; a.depth_key = g.depth_key; a.iota = g.iota;
+    a.rot_aligned16 = rotations && ((size_t)rotations % 16 == 0);
     a.clamped = g.clamped; a.rect = g.rect; a.radii = radii;
     a.tanfovx = cam.tanfovx; a.tanfovy = cam.tanfovy;
     a.focal_x = (float)cam.image_width / (2.0f * cam.tanfovx);
@@ -272,7 +344,11 @@ int launch_preprocess_forward(const mgs_camera& cam, int P, const float* means3D
     a.gx = tiles_x(a.W); a.gy = tiles_y(a.H); a.deg = cam.sh_degree; a.M = cam.sh_coeffs;
     if (P == 0) return 0;
     radix_zero_region(g.sort_temp, (uint64_t)P, 32, &a.zero_ptr, &a.zero_words);
-    hipLaunchKernelGGL(preprocess_forward_kernel, dim3((P + 255) / 256), dim3(256), 0, s, a);
+    const dim3 grid((P + 255) / 256), block(256);
+    if (cov3D_precomp && colors_precomp) hipLaunchKernelGGL((preprocess_forward_kernel<true, true>), grid, block, 0, s, a);
+    else if (cov3D_precomp) hipLaunchKernelGGL((preprocess_forward_kernel<true, false>), grid, block, 0, s, a);
+    else if (colors_precomp) hipLaunchKernelGGL((preprocess_forward_kernel<false, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((preprocess_forward_kernel<false, false>), grid, block, 0, s, a);
     MGS_HIP(hipGetLastError());
     return 0;
 }
@@ -288,6 +364,7 @@ struct BwdArgs {
     float tanfovx, tanfovy, focal_x, focal_y, mod;
     int P, W, H, deg, M;
     int iso;                  // scales / dL_dscales hold ONE float per Gaussian
+    int rot_aligned16, drot_aligned16;     // rotations / dL_drotations may be accessed 16 bytes at a time
 };
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -298,47 +375,54 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 // SH = false: colours are precomputed (MonoGS's path) -- the spherical-harmonics backward is compiled out,
 // which takes the kernel from 168 to far fewer VGPRs (occupancy) on the path that matters.
-template <bool SH>
+template <bool SH, bool COV>
 __global__ void __launch_bounds__(256) geom_backward_kernel(BwdArgs a) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int idx = blockIdx.x * 256 + threadIdx.x;        // (launched with 256 threads; blockDim would be a packet fetch)
     float tau[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const bool live = idx < a.P && a.g.radii[idx] > 0;
+    const bool in = idx < a.P;
+    const size_t ci = in ? (size_t)idx : 0;                // clamped index: the lanes past P load element 0 and ignore it
+    // ---- every input is requested up front -- camera block (scalar loads), radius, mean, covariance or scale +
+    //      rotation, opacity and the Gaussian's 64-byte line of blend sums (three 16-byte loads) -- so that the kernel
+    //      waits for memory ONCE.  Loads placed behind `radii > 0` and behind each other's first use used to cost five
+    //      dependent round trips (78 % of the wave-cycles were s_waitcnt, profiles/r02); the line of a culled Gaussian
+    //      that this reads for nothing is cheaper than a round trip.
+    Cam c;
+    load_cam(c, a.V, a.PM, a.PR, a.campos);
+    c.tanfovx = a.tanfovx; c.tanfovy = a.tanfovy; c.focal_x = a.focal_x; c.focal_y = a.focal_y;
+    const int rad = a.g.radii[ci];
+    const float x = a.g.means3D[3 * ci], y = a.g.means3D[3 * ci + 1], z = a.g.means3D[3 * ci + 2];
+    const float opq = a.g.opacities[ci];
+    const float4* gl = reinterpret_cast<const float4*>(a.g.grad_acc + ci * GRAD_FLOATS);
+    const float4 ga0 = gl[0], ga1 = gl[1], ga2 = gl[2];
+    float cov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, Mm[9];
+    float s[3] = {0.f, 0.f, 0.f}, q[4] = {1.f, 0.f, 0.f, 0.f};
+    if (COV) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) cov[k] = a.g.cov3D_precomp[6 * ci + k];
+        asm volatile("" ::"v"(cov[0]), "v"(cov[1]), "v"(cov[2]), "v"(cov[3]), "v"(cov[4]), "v"(cov[5]));
+    } else {
+        const float* sp = a.g.scales + (a.iso ? ci : 3 * ci);       // isotropic: the same address three times, no branch
+        const int o1 = a.iso ? 0 : 1, o2 = a.iso ? 0 : 2;
+        s[0] = sp[0]; s[1] = sp[o1]; s[2] = sp[o2];
+        load4(a.g.rotations + 4 * ci, a.rot_aligned16 != 0, q);
+        asm volatile("" ::"v"(s[0]), "v"(s[1]), "v"(s[2]), "v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(q[3]));
+    }
+    asm volatile("" ::"v"(rad), "v"(x), "v"(y), "v"(z), "v"(opq), "v"(ga0.x), "v"(ga0.y), "v"(ga0.z), "v"(ga0.w), "v"(ga1.x),
+                 "v"(ga1.y), "v"(ga1.z), "v"(ga1.w), "v"(ga2.x), "v"(ga2.y));
+    pin_cam(c, true);
+    const float ga[GRAD_FLOATS] = {ga0.x, ga0.y, ga0.z, ga0.w, ga1.x, ga1.y, ga1.z, ga1.w, ga2.x, ga2.y, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const bool live = in && rad > 0;
     // The [P,3] outputs (means2D, means3D, colours, anisotropic scales) are collected here and stored at the end through a
     // per-wave LDS transpose: a lane writing its own 12 bytes makes every store instruction touch 12 cache lines a
     // third each; transposed, each store is 256 contiguous bytes.  Zero for culled Gaussians.
     float o_m2[2] = {0.f, 0.f}, o_m3[3] = {0.f, 0.f, 0.f}, o_col[3] = {0.f, 0.f, 0.f}, o_sc[3] = {0.f, 0.f, 0.f};
-    if (idx < a.P) {
-        // defaults for culled Gaussians: every gradient is zero
-        if (!live) {
-            if (a.g.dL_dopacity) a.g.dL_dopacity[idx] = 0.f;
-            if (a.g.dL_dcov3D) for (int k = 0; k < 6; ++k) a.g.dL_dcov3D[6 * idx + k] = 0.f;
-            if (a.g.dL_dscales && a.iso) a.g.dL_dscales[idx] = 0.f;
-            if (a.g.dL_drotations) for (int k = 0; k < 4; ++k) a.g.dL_drotations[4 * idx + k] = 0.f;
-            if (a.g.dL_dsh) for (int k = 0; k < a.M * 3; ++k) a.g.dL_dsh[(size_t)idx * a.M * 3 + k] = 0.f;
-        }
-    }
+    float o_rot[4] = {0.f, 0.f, 0.f, 0.f}, o_cov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, o_opac = 0.f, o_siso = 0.f;
+    if (in && !live && a.g.dL_dsh) for (int k = 0; k < a.M * 3; ++k) a.g.dL_dsh[(size_t)idx * a.M * 3 + k] = 0.f;
     if (live) {
-        Cam c;
-        load_cam(c, a.V, a.PM, a.PR, a.campos);
-        c.tanfovx = a.tanfovx; c.tanfovy = a.tanfovy; c.focal_x = a.focal_x; c.focal_y = a.focal_y;
-        const float* ga = a.g.grad_acc + (size_t)idx * GRAD_FLOATS;
-        const float x = a.g.means3D[3 * idx], y = a.g.means3D[3 * idx + 1], z = a.g.means3D[3 * idx + 2];
         float pv[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) pv[k] = dot3p(c.V[k], c.V[4 + k], c.V[8 + k], c.V[12 + k], x, y, z);
-
-        float cov[6], Mm[9];
-        float s[3] = {0, 0, 0}, q[4] = {1, 0, 0, 0};
-        if (a.g.cov3D_precomp) {
-#pragma unroll
-            for (int k = 0; k < 6; ++k) cov[k] = a.g.cov3D_precomp[6 * idx + k];
-        } else {
-            if (a.iso) { s[0] = s[1] = s[2] = a.g.scales[idx]; }
-            else { s[0] = a.g.scales[3 * idx]; s[1] = a.g.scales[3 * idx + 1]; s[2] = a.g.scales[3 * idx + 2]; }
-            q[0] = a.g.rotations[4 * idx]; q[1] = a.g.rotations[4 * idx + 1];
-            q[2] = a.g.rotations[4 * idx + 2]; q[3] = a.g.rotations[4 * idx + 3];
-            cov3d_from_scale_rot(s, q, a.mod, cov, Mm);
-        }
+        if (!COV) cov3d_from_scale_rot(s, q, a.mod, cov, Mm);
         Proj p;
         project_cov(c, pv, cov, p);
 
@@ -348,7 +432,6 @@ __global__ void __launch_bounds__(256) geom_backward_kernel(BwdArgs a) {
         const float det_q = p.cxx * p.cyy - p.cxy * p.cxy;
         const float det_inv_q = 1.f / det_q;
         const float qa = p.cyy * det_inv_q, qb = -p.cxy * det_inv_q, qc = p.cxx * det_inv_q;
-        const float opq = a.g.opacities[idx];
         // raw moments -> gradients w.r.t. the conic entries and the pixel-space mean (see common.h)
         const float gA = -0.5f * opq * ga[G_SXX], gBh = 0.5f * (-opq * ga[G_SXY]), gC = -0.5f * opq * ga[G_SYY];
         // N = G Q
@@ -482,7 +565,7 @@ __global__ void __launch_bounds__(256) geom_backward_kernel(BwdArgs a) {
             for (int i = 0; i < 3; ++i)
                 tau[i] += (c.V[i] * gmean_w[0] + c.V[4 + i] * gmean_w[1]) + c.V[8 + i] * gmean_w[2];
         }
-        if (a.g.dL_dopacity) a.g.dL_dopacity[idx] = ga[G_SH];
+        o_opac = ga[G_SH];
 
         // ---- world-space mean:  p_c = Rv p + t
         if (a.g.dL_dmeans3D) {
@@ -504,12 +587,9 @@ __global__ void __launch_bounds__(256) geom_backward_kernel(BwdArgs a) {
         }
 
         // ---- Sigma = M M^T, M = R diag(mod*s)
-        if (a.g.cov3D_precomp) {
-            if (a.g.dL_dcov3D) {
-                float* o = a.g.dL_dcov3D + 6 * idx;
-                o[0] = Gs[0][0]; o[1] = 2.f * Gs[0][1]; o[2] = 2.f * Gs[0][2];
-                o[3] = Gs[1][1]; o[4] = 2.f * Gs[1][2]; o[5] = Gs[2][2];
-            }
+        if (COV) {
+            o_cov[0] = Gs[0][0]; o_cov[1] = 2.f * Gs[0][1]; o_cov[2] = 2.f * Gs[0][2];
+            o_cov[3] = Gs[1][1]; o_cov[4] = 2.f * Gs[1][2]; o_cov[5] = Gs[2][2];
         } else {
             float dM[9];
 #pragma unroll
@@ -527,7 +607,7 @@ __global__ void __launch_bounds__(256) geom_backward_kernel(BwdArgs a) {
 #pragma unroll
                 for (int j = 0; j < 3; ++j)
                     ds[j] = a.mod * ((dM[j] * Rm[j] + dM[3 + j] * Rm[3 + j]) + dM[6 + j] * Rm[6 + j]);
-                if (a.iso) a.g.dL_dscales[idx] = (ds[0] + ds[1]) + ds[2];       // backward of the isotropic expansion
+                if (a.iso) o_siso = (ds[0] + ds[1]) + ds[2];                    // backward of the isotropic expansion
                 else { o_sc[0] = ds[0]; o_sc[1] = ds[1]; o_sc[2] = ds[2]; }
             }
             if (a.g.dL_drotations) {
@@ -544,12 +624,24 @@ __global__ void __launch_bounds__(256) geom_backward_kernel(BwdArgs a) {
                                   4.f * qy * (dR[0] + dR[8]);
                 const float dqz = 2.f * (r * (dR[3] - dR[1]) + qx * (dR[2] + dR[6]) + qy * (dR[5] + dR[7])) -
                                   4.f * qz * (dR[0] + dR[4]);
-                float* o = a.g.dL_drotations + 4 * idx;
-                o[0] = dr; o[1] = dqx; o[2] = dqy; o[3] = dqz;
+                o_rot[0] = dr; o_rot[1] = dqx; o_rot[2] = dqy; o_rot[3] = dqz;
             }
         }
     }
-    // ---- block reduction of the 6 pose components, one atomic per block and component
+    if (in) {   // ---- per-Gaussian outputs whose rows are 4, 16 or 24 bytes: one store each (zeros for culled Gaussians)
+        if (a.g.dL_dopacity) a.g.dL_dopacity[idx] = o_opac;
+        if (a.g.dL_dscales && a.iso) a.g.dL_dscales[idx] = o_siso;
+        if (a.g.dL_drotations) {
+            float* o = a.g.dL_drotations + 4 * (size_t)idx;
+            if (a.drot_aligned16) *reinterpret_cast<float4*>(o) = make_float4(o_rot[0], o_rot[1], o_rot[2], o_rot[3]);
+            else { o[0] = o_rot[0]; o[1] = o_rot[1]; o[2] = o_rot[2]; o[3] = o_rot[3]; }
+        }
+        if (COV && a.g.dL_dcov3D) {
+            float* o = a.g.dL_dcov3D + 6 * (size_t)idx;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) o[k] = o_cov[k];
+        }
+    }
     {   // ---- transposed stores of the three-float outputs (every lane of the wave takes part)
         __shared__ float s_stage[4][3 * WAVE];
         const int lane = threadIdx.x & 63;
@@ -600,17 +692,21 @@ int launch_geom_backward(const mgs_camera& cam, int P, const GeometryState& g, c
     a.iso = cam.scale_dim == 1;
     a.P = P; a.W = cam.image_width; a.H = cam.image_height; a.deg = cam.sh_degree; a.M = cam.sh_coeffs;
     if (P == 0) return 0;
-    if (ga.colors_precomp)
-        hipLaunchKernelGGL(geom_backward_kernel<false>, dim3((P + 255) / 256), dim3(256), 0, s, a);
-    else
-        hipLaunchKernelGGL(geom_backward_kernel<true>, dim3((P + 255) / 256), dim3(256), 0, s, a);
+    a.rot_aligned16 = ga.rotations && ((size_t)ga.rotations % 16 == 0);
+    a.drot_aligned16 = ga.dL_drotations && ((size_t)ga.dL_drotations % 16 == 0);
+    const dim3 grid((P + 255) / 256), block(256);
+    const bool cov = ga.cov3D_precomp != nullptr;
+    if (ga.colors_precomp && cov) hipLaunchKernelGGL((geom_backward_kernel<false, true>), grid, block, 0, s, a);
+    else if (ga.colors_precomp) hipLaunchKernelGGL((geom_backward_kernel<false, false>), grid, block, 0, s, a);
+    else if (cov) hipLaunchKernelGGL((geom_backward_kernel<true, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((geom_backward_kernel<true, false>), grid, block, 0, s, a);
     MGS_HIP(hipGetLastError());
     return 0;
 }
 
 // =================================================================================================
 __global__ void mark_visible_kernel(int P, const float* means3D, const float* V, uint8_t* visible) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int idx = blockIdx.x * 256 + threadIdx.x;        // (launched with 256 threads; blockDim would be a packet fetch)
     if (idx >= P) return;
     const float x = means3D[3 * idx], y = means3D[3 * idx + 1], z = means3D[3 * idx + 2];
     const float vz = dot3p(V[2], V[6], V[10], V[14], x, y, z);

@@ -28,5 +28,10 @@ for k in sorted(set(fetch) | set(write)):
     out[k] = {"fetch_kib_raw": round(fetch.get(k, 0), 1), "write_kib_raw": round(write.get(k, 0), 1),
               "hbm_bytes": int(2 * fetch.get(k, 0) * 1024 + write.get(k, 0) * 1024)}
 out["blend_backward_bytes_per_launch"] = out.get("blend_backward_kernel", {}).get("hbm_bytes")
+# identity of the kernel sources these counters were collected on (bench.py ignores the file when it does not match)
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import csrc_hash  # noqa: E402
+out["csrc_sha256"] = csrc_hash()
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out, indent=1))

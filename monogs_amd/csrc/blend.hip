@@ -103,11 +103,14 @@ __global__ void __launch_bounds__(256) blend_forward_kernel(BlendArgs a, float* 
     const float qx0 = (float)qx0i, qy0 = (float)qy0i;
     const uint2 range = a.ranges[tile];
 
-    // T is the running transmittance and doubles as the "still blending" flag: a pixel that
-    // terminates (or lies outside the image) gets T = 0, after which every later instance fails the
-    // T(1-alpha) >= 1e-4 test by itself and contributes w = alpha*T = 0.  Tf keeps the value to store.
-    float T = inside ? 1.f : 0.f, Tf = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f;
+    // T is the running transmittance.  Which pixels are still blending is a 64-bit lane mask kept in scalar registers
+    // (`live`): every per-pixel decision below is a v_cmp that writes a lane mask, the masks are combined on the scalar
+    // unit, and __builtin_amdgcn_inverse_ballot_w64 hands a mask back to v_cndmask as its condition -- no predicate is
+    // ever materialised in a VGPR (a ballot of a compound bool compiled to v_cndmask 0/1 + v_cmp_ne, twice per
+    // survivor, and the "done" state cost three selects on T / Tf).  A pixel outside the image never blends.
+    float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f;
     uint32_t last = 0;
+    unsigned long long live = __builtin_amdgcn_ballot_w64(inside);
 
     uint32_t gid_n = 0;
     float4 box_n = make_float4(0.f, 0.f, -1.f, -1.f), ell_n = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -121,14 +124,11 @@ __global__ void __launch_bounds__(256) blend_forward_kernel(BlendArgs a, float* 
         }
     };
     if (range.x < range.y) prefetch(range.x + lane);
-    for (uint32_t base = range.x; base < range.y; base += WAVE) {
+    for (uint32_t base = range.x; base < range.y && live != 0ull; base += WAVE) {
         const uint32_t gid_l = gid_n;
         const float4 c = box_n, el = ell_n;
         prefetch(base + WAVE + lane);
-        const unsigned long long alive = __builtin_amdgcn_ballot_w64(T != 0.f);      // pixels still blending
-        const bool hit = quadrant_hit(c, el, qx0, qy0, alive);
-        unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
-        bool all_done = false;
+        unsigned long long mask = __builtin_amdgcn_ballot_w64(quadrant_hit(c, el, qx0, qy0, live));
         while (mask) {
             const int j = __builtin_ctzll(mask);
             mask &= mask - 1;
@@ -137,29 +137,27 @@ __global__ void __launch_bounds__(256) blend_forward_kernel(BlendArgs a, float* 
             const float dx = g.px - pxf, dy = g.py - pyf;
             const float power = dx * (g.ca * dx + g.cb * dy) + (g.cc * dy) * dy;     // log2 of the Gaussian falloff
             const float alpha = fminf(0.99f, g.op * __builtin_amdgcn_exp2f(power));
-            const bool act = !(power > 0.f) && !(alpha < 1.0f / 255.0f);
             const float test_T = T * (1.f - alpha);
-            const bool stop = act && (test_T < 0.0001f);
-            const bool contrib = act && !stop;
-            const float w = contrib ? alpha * T : 0.f;
+            const unsigned long long act = live & __builtin_amdgcn_ballot_w64(!(power > 0.f)) &
+                                           __builtin_amdgcn_ballot_w64(!(alpha < 1.0f / 255.0f));
+            const unsigned long long low = __builtin_amdgcn_ballot_w64(test_T < 0.0001f);
+            const unsigned long long stop = act & low, contrib = act & ~low;
+            live &= ~stop;                                                 // terminated: this instance is NOT blended
+            const bool cb = __builtin_amdgcn_inverse_ballot_w64(contrib);
+            const float w = cb ? alpha * T : 0.f;
             C0 += g.r * w;
             C1 += g.g * w;
             C2 += g.b * w;
             D += g.z * w;
-            Tf = contrib ? test_T : Tf;
-            T = stop ? 0.f : (contrib ? test_T : T);
-            last = contrib ? (base - range.x) + (uint32_t)j + 1u : last;
-            const unsigned long long touched = __builtin_amdgcn_ballot_w64(contrib && test_T > 0.5f);
-            if (touched) {
+            T = cb ? test_T : T;
+            last = cb ? (base - range.x) + (uint32_t)j + 1u : last;
+            const unsigned long long touched = contrib & __builtin_amdgcn_ballot_w64(test_T > 0.5f);
+            if (touched != 0ull) {
                 if (lane == 0) atomicAdd(n_touched + gid, (int)__popcll(touched));
             }
-            if (__builtin_amdgcn_ballot_w64(stop)) {                      // rare: re-check whether the whole quadrant is finished
-                if (__builtin_amdgcn_ballot_w64(T != 0.f) == 0ull) { all_done = true; break; }
-            }
+            if (live == 0ull) break;                                       // the whole quadrant is finished
         }
-        if (all_done) break;
     }
-    T = Tf;
     if (inside) {
         const size_t pix = (size_t)pyi * a.W + pxi, HW = (size_t)a.H * a.W;
         final_T[pix] = T;

@@ -81,10 +81,13 @@ __device__ __forceinline__ bool quadrant_hit(const float4 c /* px, py, ex, ey */
 struct Rec {
     float px, py, ca, cb, cc, op, r, g, b, z;
 };
+// Read through the CONSTANT address space (common.h): the backend then always selects scalar loads for the wave-uniform
+// address (s_load_dwordx2 + s_load_dwordx8).  Through the generic pointer that choice hangs on a no-clobber analysis that
+// flips to per-lane vector loads with unrelated edits of the loop (an atomic moved, an LDS store added).  The records
+// are written by preprocess, an earlier kernel.
 __device__ __forceinline__ Rec fetch(const BlendArgs& a, uint32_t gid_uniform) {
-    const float4* p = a.rec + (size_t)gid_uniform * 4;
-    const float4 r0 = p[0], r1 = p[1], r2 = p[2];
-    return Rec{r0.x, r0.y, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
+    const const_float_p p = MGS_CONST(reinterpret_cast<const float*>(a.rec)) + (size_t)gid_uniform * REC_FLOATS;
+    return Rec{p[R_X], p[R_Y], p[R_CA], p[R_CB], p[R_CC], p[R_OPAC], p[R_R], p[R_G], p[R_B], p[R_DEPTH]};
 }
 
 __global__ void __launch_bounds__(256) blend_forward_kernel(BlendArgs a, float* __restrict__ out_color,
@@ -129,9 +132,12 @@ __global__ void __launch_bounds__(256) blend_forward_kernel(BlendArgs a, float* 
         const float4 c = box_n, el = ell_n;
         prefetch(base + WAVE + lane);
         unsigned long long mask = __builtin_amdgcn_ballot_w64(quadrant_hit(c, el, qx0, qy0, live));
+        // n_touched of this step's instances, collected in lane j of one register (v_writelane: one instruction, no
+        // branch) and added with ONE vector atomic per step instead of a guarded lane-0 atomic per touched survivor
+        int touched_cnt = 0;
         while (mask) {
             const int j = __builtin_ctzll(mask);
-            mask &= mask - 1;
+            mask &= ~(1ull << j);
             const uint32_t gid = bcast(gid_l, j);
             const Rec g = fetch(a, gid);
             const float dx = g.px - pxf, dy = g.py - pyf;
@@ -152,11 +158,10 @@ __global__ void __launch_bounds__(256) blend_forward_kernel(BlendArgs a, float* 
             T = cb ? test_T : T;
             last = cb ? (base - range.x) + (uint32_t)j + 1u : last;
             const unsigned long long touched = contrib & __builtin_amdgcn_ballot_w64(test_T > 0.5f);
-            if (touched != 0ull) {
-                if (lane == 0) atomicAdd(n_touched + gid, (int)__popcll(touched));
-            }
+            touched_cnt = lane == j ? (int)__popcll(touched) : touched_cnt;   // (v_writelane takes one scalar operand only)
             if (live == 0ull) break;                                       // the whole quadrant is finished
         }
+        if (touched_cnt != 0) atomicAdd(n_touched + gid_l, touched_cnt);
     }
     if (inside) {
         const size_t pix = (size_t)pyi * a.W + pxi, HW = (size_t)a.H * a.W;

@@ -13,6 +13,6 @@ for p in a b; do
   rm -rf /tmp/pmc_$tag_$p
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/pmc_${tag}_$p -o c -- python3 $R/bench.py --no-cpu-baseline --no-slam --steps 3 --warmup 1 > /tmp/pmc_${tag}_$p.log 2>&1
   f=$(find /tmp/pmc_${tag}_$p -name '*counter_collection.csv' | head -1)
-  python3 $R/tools/pmc_table.py $f blend > $R/gpurun_out/pmc_${tag}_$p.txt 2>&1 || tail -5 /tmp/pmc_${tag}_$p.log
+  python3 $R/tools/pmc_table.py $f ${PMC_FILTER:-blend} > $R/gpurun_out/pmc_${tag}_$p.txt 2>&1 || tail -5 /tmp/pmc_${tag}_$p.log
 done
 cat $R/gpurun_out/pmc_${tag}_a.txt $R/gpurun_out/pmc_${tag}_b.txt

@@ -166,7 +166,7 @@ int mgs_forward_preprocess(const mgs_camera* cam, int32_t P, const float* means3
     tm.mark();
     if (num_rendered) {
         uint32_t total = 0, sort_errors[RADIX_ERROR_WORDS] = {0, 0, 0, 0};
-        MGS_HIP(hipMemcpyAsync(&total, g.point_offsets + (P - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        MGS_HIP(hipMemcpyAsync(&total, g.scan_blocks + scan_nblocks(P), sizeof(uint32_t), hipMemcpyDeviceToHost, s));   // grand total
         MGS_HIP(hipMemcpyAsync(sort_errors, radix_error_flag(g.sort_temp, (uint64_t)P, 32), sizeof(sort_errors),
                                hipMemcpyDeviceToHost, s));
         MGS_HIP(hipStreamSynchronize(s));

@@ -18,10 +18,11 @@
 namespace mgs {
 
 // ------------------------------------------------------------------------------------------------
-// inclusive scan of uint32, three launches: per-block reduce+local scan, scan of block sums, add.
-// 256 threads x 8 items.
+// inclusive scan of uint32 in two launches: per-block local scan + block sums, exclusive scan of the block sums
+// (+ the grand total).  Global offset of element i = local[i] + block_sums[i / SCAN_ITEMS].  256 threads x 8 items.
 // ------------------------------------------------------------------------------------------------
 constexpr int SCAN_THREADS = 256;
+__device__ __forceinline__ int scan_nblocks_dev(int P) { return (P + SCAN_ITEMS - 1) / SCAN_ITEMS; }
 constexpr int SCAN_PER_THREAD = SCAN_ITEMS / SCAN_THREADS;
 
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int) { return wave_incl_scan_dpp(v); }
@@ -74,15 +75,11 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_blocks_kernel(uint32_t* blo
         if (i < nblocks) block_sums[i] = carry + ex;
         carry += total;
     }
+    if (threadIdx.x == 0) block_sums[nblocks] = carry;      // grand total = number of instances R (read back by the exact path)
 }
 
-__global__ void __launch_bounds__(SCAN_THREADS) scan_add_kernel(uint32_t* out, const uint32_t* block_sums, int n) {
-    const uint32_t add = block_sums[blockIdx.x];
-    const int base = blockIdx.x * SCAN_ITEMS + threadIdx.x * SCAN_PER_THREAD;
-#pragma unroll
-    for (int i = 0; i < SCAN_PER_THREAD; ++i)
-        if (base + i < n) out[base + i] += add;
-}
+// (There is no third "add the block offset" pass: the only consumer of the offsets, duplicate_kernel, adds
+//  block_sums[i / SCAN_ITEMS] itself -- one launch and a 16-byte-per-Gaussian read-modify-write less.)
 
 // (Measured and rejected: a single-workgroup scan for small P -- 1024 threads x a serial run of dependent
 //  gathers each -- took ~300 us at P = 38 k against ~15 us for the three launches below: latency, not launches.)
@@ -91,10 +88,7 @@ int launch_scan(const GeometryState& g, int P, hipStream_t s) {
     const int nb = scan_nblocks(P);
     hipLaunchKernelGGL(scan_local_kernel, dim3(nb), dim3(SCAN_THREADS), 0, s, g.rect_sorted, g.point_offsets,
                        g.scan_blocks, P);
-    if (nb > 1) {
-        hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(SCAN_THREADS), 0, s, g.scan_blocks, nb);
-        hipLaunchKernelGGL(scan_add_kernel, dim3(nb), dim3(SCAN_THREADS), 0, s, g.point_offsets, g.scan_blocks, P);
-    }
+    hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(SCAN_THREADS), 0, s, g.scan_blocks, nb);
     MGS_HIP(hipGetLastError());
     return 0;
 }
@@ -105,7 +99,9 @@ int launch_scan(const GeometryState& g, int P, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) duplicate_kernel(int P, const uint2* __restrict__ rects,
                                                         const uint32_t* __restrict__ perm,
-                                                        const uint32_t* __restrict__ offsets, uint32_t* keys,
+                                                        const uint32_t* __restrict__ offsets /* block-local inclusive sums */,
+                                                        const uint32_t* __restrict__ block_sums /* [nb] exclusive, [nb] = total */,
+                                                        uint32_t* keys,
                                                         uint32_t* vals, int gx, int gy, uint32_t r_cap,
                                                         int32_t* __restrict__ n_touched, uint2* __restrict__ ranges,
                                                         int ntiles, uint32_t* __restrict__ zero_ptr, size_t zero_words,
@@ -121,7 +117,7 @@ __global__ void __launch_bounds__(256) duplicate_kernel(int P, const uint2* __re
     // count is published as 0, so the tile sort, the ranges and the blend kernels have nothing to do either)
     const bool depth_bad = depth_err && radix_failed(depth_err) != 0u;
     if (i == 0 && count) {                               // capacity mode: live instance count + overflow flag (was a launch)
-        const uint32_t R = (P > 0 && !depth_bad) ? offsets[P - 1] : 0u;
+        const uint32_t R = (P > 0 && !depth_bad) ? block_sums[scan_nblocks_dev(P)] : 0u;
         count[0] = min(R, r_cap);
         count[1] = R > r_cap ? 1u : 0u;
     }
@@ -141,7 +137,7 @@ __global__ void __launch_bounds__(256) duplicate_kernel(int P, const uint2* __re
         x0 = (int)(r.x & 0xFFFFu); y0 = (int)(r.x >> 16); x1 = x0 + w;
     }
     if (depth_bad) nt = 0;                               // (wave-uniform, grid-uniform)
-    if (nt) off = i == 0 ? 0u : offsets[i - 1];
+    if (nt) off = i == 0 ? 0u : offsets[i - 1] + block_sums[(i - 1) / SCAN_ITEMS];
     // Load-balanced emission.  The 64 Gaussians of the wave own the consecutive output slots [S, E); the wave walks
     // that range 64 slots at a time (aligned, so every store is one coalesced 256-byte line) and each lane finds the
     // owner of its slot: owners mark their first slot in LDS, an inclusive max-scan spreads the mark to the right.
@@ -193,7 +189,7 @@ int launch_duplicate(const mgs_camera& cam, int P, const GeometryState& g, const
     size_t zero_words = 0;
     if (sort_n > 0) radix_zero_region(b.sort_temp, sort_n, sort_bits, &zero_ptr, &zero_words);
     hipLaunchKernelGGL(duplicate_kernel, dim3((n + 255) / 256), dim3(256), 0, s, P, g.rect_sorted, g.perm, g.point_offsets,
-                       b.keys_a, b.vals_a, tiles_x(cam.image_width), tiles_y(cam.image_height),
+                       g.scan_blocks, b.keys_a, b.vals_a, tiles_x(cam.image_width), tiles_y(cam.image_height),
                        (uint32_t)(r_cap > 0xFFFFFFFFull ? 0xFFFFFFFFull : r_cap), n_touched, img.ranges, ntiles, zero_ptr,
                        zero_words, count, overflow, depth_err);
     MGS_HIP(hipGetLastError());

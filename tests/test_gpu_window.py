@@ -65,6 +65,61 @@ def _run_window(rank, world, port, out):
         dist.destroy_process_group()
 
 
+def _run_densify(rank, world, port, out):
+    """Map surgery inside the sharded window: densify_and_prune on iterations 2 and 4 (clone + split with the seeded
+    generator + prune), opacity reset of the non-visible on iteration 5, covisibility prune at the end."""
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from monogs_amd.gaussian_map import GaussianMap
+    from monogs_amd.mapping import WindowMapper
+    from monogs_amd.slam_harness import make_sequence
+    from monogs_amd.window import replicas_in_sync
+
+    dev = "cuda:0"
+    torch.cuda.set_device(0)
+    if world > 1:
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    frames, intr = make_sequence(N_KF, "fr3_office", n_gaussians=20000, device=dev)
+    for vp in frames:
+        vp.update_RT(vp.R_gt.clone(), vp.T_gt.clone())
+    gmap = GaussianMap(dev)
+    gmap.extend_from_frame(frames[0], intr, downsample=16, init=True, point_size=1.0)
+    n0 = len(gmap)
+    mapper = WindowMapper(gmap, intr, torch.zeros(3, device=dev), window_size=N_KF, seed=7)
+    mapper.gaussian_update_every, mapper.gaussian_update_offset = 2, 0      # densify on iterations 2, 4
+    mapper.gaussian_reset = 5                                                # opacity reset on iteration 5
+    mapper.densify_grad_threshold = 1e-7                                     # so that clone AND split really fire
+    mapper.gaussian_th = 0.05                                                # (0.7 would prune the whole young map: opacities start at 0.5)
+    sizes = []
+    for _ in range(5):
+        mapper.optimize_map(frames, iters=1)
+        sizes.append(len(gmap))
+    mapper.optimize_map(frames, prune=True, iters=1)                         # full window: covisibility prune
+    sizes.append(len(gmap))
+    ok = replicas_in_sync(gmap.params() + [gmap.xyz_gradient_accum, gmap.denom, gmap.max_radii_2d,
+                                           gmap.kf_idx.float(), gmap.nr_obs.float()] + gmap.optimizer.exp_avg)
+    torch.save(dict(n0=n0, sizes=sizes, in_sync=ok, steps=gmap.optimizer.t_dev.cpu(),
+                    vis_len=[int(v.shape[0]) for v in mapper.occ_aware_visibility.values()],
+                    finite=all(bool(torch.isfinite(p).all()) for p in gmap.params())), f"{out}.d{world}.{rank}")
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_two_rank_map_surgery_stays_in_sync(native_lib, tmp_path):
+    """Densification (clone, seeded split, prune), opacity reset and covisibility pruning change the map size inside the
+    sharded window; the replicas must go through them identically with no parameter broadcast."""
+    out = str(tmp_path / "w")
+    mp.spawn(_run_densify, args=(2, _free_port(), out), nprocs=2, join=True)
+    r0, r1 = torch.load(f"{out}.d2.0"), torch.load(f"{out}.d2.1")
+    assert r0["in_sync"] and r1["in_sync"] and r0["finite"]
+    assert r0["sizes"] == r1["sizes"]
+    assert r0["sizes"][1] != r0["n0"] and r0["sizes"][3] != r0["sizes"][2], r0["sizes"]      # both densify steps changed the map
+    assert all(n == r0["sizes"][-1] for n in r0["vis_len"]) and len(r0["vis_len"]) == N_KF    # visibility re-indexed by the prune
+    assert torch.equal(r0["steps"], r1["steps"])
+
+
 def _rel(a, b):
     return ((a.double() - b.double()).norm() / (b.double().norm() + 1e-30)).item()
 

@@ -44,7 +44,11 @@ def _run_hip(sc, inp, st):
     return [o.detach().cpu() for o in out], grads
 
 
-def _check_grads(grads, ograds, rtol=1e-3, max_outlier_frac=2e-4):
+def _check_grads(grads, ograds, rtol=1e-3, max_outlier_frac=2e-4, l2_tol=1e-4):
+    """north_star: gradient rtol <= 1e-3.  Held here as (i) relative L2 error of every gradient tensor <= 1e-4 (measured:
+    ~1e-6), ten times inside the bar, and (ii) ELEMENTWISE |got - ref| <= 1e-3 |ref| + 1e-5 max|ref| for all but a
+    2e-4 fraction of the elements: a pixel whose alpha or transmittance sits within an ulp of a threshold may take
+    the other branch on the GPU (different exp / rounding), which moves the handful of gradient entries it feeds."""
     report = {}
     for k, ref in ograds.items():
         got = grads[k].reshape(ref.shape).double()
@@ -54,9 +58,9 @@ def _check_grads(grads, ograds, rtol=1e-3, max_outlier_frac=2e-4):
             assert got.abs().max().item() == 0, k
             continue
         rel_l2 = ((got - ref).norm() / ref.norm()).item()
-        bad = ((got - ref).abs() > rtol * ref.abs() + 1e-4 * scale)
+        bad = ((got - ref).abs() > rtol * ref.abs() + 1e-5 * scale)
         report[k] = (rel_l2, bad.float().mean().item())
-        assert rel_l2 <= rtol, f"{k}: relative L2 error {rel_l2:.3e}"
+        assert rel_l2 <= l2_tol, f"{k}: relative L2 error {rel_l2:.3e}"
         assert bad.float().mean().item() <= max_outlier_frac, f"{k}: {bad.sum().item()} elements off"
     return report
 

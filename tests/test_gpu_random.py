@@ -47,12 +47,13 @@ def test_random_small_scene(native_lib, W, H, P, seed, rad, aniso, bg):
         assert (out[3].cpu() - oout.opacity).abs()[0][ok].max() <= 1e-4
     grads = {k: v.grad.cpu() for k, v in leaves.items()}
     grads.update(means2D=m2d.grad.cpu(), theta=th.grad.cpu(), rho=rh.grad.cpu())
-    if (~ok).any():
-        return          # a threshold-ambiguous pixel changes a handful of gradient entries: images checked, grads skipped
+    # a threshold-ambiguous pixel may blend one instance more or less on the GPU, which changes the few gradient entries
+    # it feeds: the tensors are still compared, with the bar that one flipped pixel of these small images can move
+    l2_tol = 1e-3 if not (~ok).any() else 5e-2
     for k, ref in og.items():
         got, ref = grads[k].reshape(ref.shape).double(), ref.double()
         scale = ref.abs().max().item()
         if scale == 0:
             assert got.abs().max().item() <= 1e-12, k
             continue
-        assert ((got - ref).norm() / ref.norm()).item() <= 1e-3, k
+        assert ((got - ref).norm() / ref.norm()).item() <= l2_tol, (k, int((~ok).sum()))

@@ -129,7 +129,9 @@ const char* mgs_last_error(void) { return g_err; }
 size_t mgs_geometry_bytes(int32_t P) { return GeometryState::bytes(P < 0 ? 0 : P); }
 size_t mgs_image_bytes(int32_t W, int32_t H) { return ImageState::bytes(W, H); }
 size_t mgs_binning_bytes(uint64_t R, int32_t W, int32_t H) { return BinningState::bytes(R, W, H); }
-size_t mgs_backward_bytes(int32_t P) { return (size_t)(P < 0 ? 0 : P) * GRAD_FLOATS * sizeof(float) + 256; }
+size_t mgs_backward_bytes(int32_t P) {
+    return (size_t)(P < 0 ? 0 : P) * GRAD_FLOATS * sizeof(float) + (size_t)TAU_SLOTS * 16 * sizeof(float) + 256;
+}
 
 int mgs_forward_preprocess(const mgs_camera* cam, int32_t P, const float* means3D, const float* shs,
                            const float* colors_precomp, const float* opacities, const float* scales,
@@ -260,7 +262,10 @@ int mgs_backward(const mgs_camera* cam, int32_t P, uint64_t R, const float* mean
     BinningState b = BinningState::carve(const_cast<void*>(binning), R, W, H);
     float* grad_acc = (float*)align_up((size_t)backward_scratch, 256);
     StageTimer tm(s, timing != nullptr);
-    MGS_HIP(zero_fill2(grad_acc, (size_t)P * GRAD_FLOATS * sizeof(float), dL_dtau, 6 * sizeof(float), s));
+    // (the pose-gradient slots sit right behind the accumulator: one clear covers both)
+    float* tau_part = (dL_dtau && (P + 255) / 256 > TAU_DIRECT_MAX_BLOCKS) ? grad_acc + (size_t)P * GRAD_FLOATS : nullptr;
+    MGS_HIP(zero_fill2(grad_acc, (size_t)P * GRAD_FLOATS * sizeof(float) + (tau_part ? (size_t)TAU_SLOTS * 16 * sizeof(float) : 0),
+                       dL_dtau, 6 * sizeof(float), s));
     tm.mark();
     if (R > 0) {
         // colours / opacities take no gradient and do not feed the geometry (no SH): the lighter blend backward
@@ -274,7 +279,7 @@ int mgs_backward(const mgs_camera* cam, int32_t P, uint64_t R, const float* mean
     a.grad_acc = grad_acc;
     a.dL_dmeans2D = dL_dmeans2D; a.dL_dcolors = dL_dcolors; a.dL_dopacity = dL_dopacity;
     a.dL_dmeans3D = dL_dmeans3D; a.dL_dcov3D = dL_dcov3D; a.dL_dsh = dL_dsh; a.dL_dscales = dL_dscales;
-    a.dL_drotations = dL_drotations; a.dL_dtau = dL_dtau;
+    a.dL_drotations = dL_drotations; a.dL_dtau = dL_dtau; a.tau_part = tau_part;
     if (int rc = launch_geom_backward(*cam, P, g, a, s)) return rc;
     tm.mark();
     if (timing) {

@@ -226,7 +226,10 @@ struct GeomBackwardArgs {
     const float* grad_acc;   // [P][16] from the blend backward
     float *dL_dmeans2D, *dL_dcolors, *dL_dopacity, *dL_dmeans3D, *dL_dcov3D, *dL_dsh, *dL_dscales,
         *dL_drotations, *dL_dtau;
+    float* tau_part;         // [TAU_SLOTS][16] zeroed partial pose gradients (large launches), or NULL: add into dL_dtau directly
 };
+constexpr int TAU_SLOTS = 256;              // one 64-byte line each
+constexpr int TAU_DIRECT_MAX_BLOCKS = 256;  // up to this many workgroups the direct same-address adds are cheaper than a launch
 int launch_geom_backward(const mgs_camera& cam, int P, const GeometryState& g, const GeomBackwardArgs& a,
                          hipStream_t s);
 int launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* visible, hipStream_t s);

@@ -642,21 +642,10 @@ __global__ void __launch_bounds__(256) geom_backward_kernel(BwdArgs a) {
             for (int k = 0; k < 6; ++k) o[k] = o_cov[k];
         }
     }
-    {   // ---- transposed stores of the three-float outputs (every lane of the wave takes part)
-        __shared__ float s_stage[4][3 * WAVE];
-        const int lane = threadIdx.x & 63;
-        float* st = s_stage[threadIdx.x >> 6];
-        const size_t base = (size_t)(idx - lane) * 3, limit = (size_t)a.P * 3;
+    if (in) {   // ---- the three-float outputs: 12 contiguous bytes per lane, 768 per wave = ONE global_store_dwordx3 each
+        struct F3 { float x, y, z; };
         auto store3 = [&](float* __restrict__ out, float v0, float v1, float v2) {
-            if (!out) return;                                   // wave-uniform
-            __builtin_amdgcn_wave_barrier();
-            st[3 * lane] = v0; st[3 * lane + 1] = v1; st[3 * lane + 2] = v2;
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const size_t o = base + (size_t)k * WAVE + lane;
-                if (o < limit) out[o] = st[k * WAVE + lane];
-            }
+            if (out) *reinterpret_cast<F3*>(out + 3 * (size_t)idx) = F3{v0, v1, v2};
         };
         store3(a.g.dL_dmeans2D, o_m2[0], o_m2[1], 0.f);
         store3(a.g.dL_dmeans3D, o_m3[0], o_m3[1], o_m3[2]);
@@ -674,9 +663,31 @@ __global__ void __launch_bounds__(256) geom_backward_kernel(BwdArgs a) {
         __syncthreads();
         if (threadIdx.x < 6) {
             const float v = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
-            if (v != 0.f) atomicAdd(a.g.dL_dtau + threadIdx.x, v);
+            // Thousands of workgroups adding into the SAME 24 bytes serialise at the memory-side atomic unit (at C5 the
+            // 7 813 x 6 same-address adds were 45 % of this kernel: 0.116 vs 0.065 ms without them).  Large launches
+            // spread them over TAU_SLOTS lines (one 64-byte line per slot) and tau_finalize_kernel adds the slots up.
+            if (v != 0.f) {
+                if (a.g.tau_part) atomicAdd(a.g.tau_part + (size_t)(blockIdx.x % TAU_SLOTS) * 16 + threadIdx.x, v);
+                else atomicAdd(a.g.dL_dtau + threadIdx.x, v);
+            }
         }
     }
+}
+
+// dL_dtau[k] = sum over the slots (one block; fixed order, so the only non-determinism left is inside a slot)
+__global__ void __launch_bounds__(256) tau_finalize_kernel(const float* __restrict__ tau_part, float* __restrict__ dL_dtau) {
+    __shared__ float part[4][6];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    float v[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) v[k] = t < TAU_SLOTS ? tau_part[(size_t)t * 16 + k] : 0.f;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const float r = wave_sum(v[k]);
+        if (lane == 0) part[wv][k] = r;
+    }
+    __syncthreads();
+    if (t < 6) dL_dtau[t] = (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
 }
 
 int launch_geom_backward(const mgs_camera& cam, int P, const GeometryState& g, const GeomBackwardArgs& ga,
@@ -700,6 +711,7 @@ int launch_geom_backward(const mgs_camera& cam, int P, const GeometryState& g, c
     else if (ga.colors_precomp) hipLaunchKernelGGL((geom_backward_kernel<false, false>), grid, block, 0, s, a);
     else if (cov) hipLaunchKernelGGL((geom_backward_kernel<true, true>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((geom_backward_kernel<true, false>), grid, block, 0, s, a);
+    if (ga.tau_part && ga.dL_dtau) hipLaunchKernelGGL(tau_finalize_kernel, dim3(1), dim3(256), 0, s, ga.tau_part, ga.dL_dtau);
     MGS_HIP(hipGetLastError());
     return 0;
 }

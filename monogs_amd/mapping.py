@@ -67,6 +67,7 @@ class WindowMapper:
         self.exposed_comm_s = 0.0       # wall time spent waiting in collectives (diagnostic, synchronises when on)
         self.time_comm = False
         self._bucket = None
+        self.map_surgery = True          # False: no densify_and_prune / opacity reset (fixed-size workloads: benchmarks, tests)
         self.keep_reduced_grads = False  # tests: clones of the (all-reduced) Gaussian gradients of the last iteration
         self.last_grads = None
 
@@ -132,13 +133,14 @@ class WindowMapper:
                 gmap.xyz_gradient_accum += d_norm
                 gmap.denom += d_vis
 
-                update_gaussian = self.nr_iters % self.gaussian_update_every == self.gaussian_update_offset
+                update_gaussian = self.map_surgery and \
+                    self.nr_iters % self.gaussian_update_every == self.gaussian_update_offset
                 if update_gaussian:
                     gmap.densify_and_prune(self.densify_grad_threshold, self.gaussian_th, self.gaussian_extent,
                                            self.size_threshold,
                                            generator=W.split_generator(gmap.device, self.seed, self.nr_iters))
                     gaussian_split = True
-                if (self.nr_iters % self.gaussian_reset) == 0 and not update_gaussian:
+                if self.map_surgery and (self.nr_iters % self.gaussian_reset) == 0 and not update_gaussian:
                     # every keyframe's visibility_filter (radii > 0); only their union matters
                     gmap.reset_opacity_nonvisible([self._union_visible(pkgs, mine, P)])
                     gaussian_split = True

@@ -18,7 +18,8 @@ def runs(native_lib):
 
 
 def test_tracking_converges_and_reduces_the_pose_error(runs):
-    eager, _ = runs
+    eager, graph = runs
+    assert graph["ate_rmse_m"] < 2e-3, graph["ate_rmse_m"]          # the end-to-end run on captured tracking iterations
     c, gt = eager["camera_centers"], eager["camera_centers_gt"]
     for i in range(1, CFG["n_frames"]):
         before = (c[i - 1] - gt[i]).norm().item()       # tracking starts from the previous frame's estimate
@@ -29,21 +30,59 @@ def test_tracking_converges_and_reduces_the_pose_error(runs):
     assert all(1 < n < CFG["tracking_itr_num"] for _, n in eager["track_iters_per_frame"]), eager["track_iters_per_frame"]
 
 
-def test_graph_tracking_equals_eager_tracking(runs):
+def test_graph_tracking_equals_eager_tracking(native_lib):
     """A captured tracking iteration replayed until the device-side convergence flag rises = the eager loop with its
-    per-iteration `if converged: break`.  The blend backward sums with float atomics, so the two runs agree to
-    rounding, not bit for bit -- and the exit test (|tau| < 1e-4 on an Adam step that hovers around that size near the
-    optimum) amplifies rounding into a few iterations more or fewer, i.e. into pose differences of the size of the exit
-    threshold itself: poses to 2e-4 (camera centres to 0.2 mm); both loops leave early, after a number of iterations
-    that differs by at most a third (observed: 61/68, 66/62, 69/56 on different boxes)."""
-    eager, graph = runs
-    assert graph["ate_rmse_m"] < 2e-3
-    for (i, ne), (j, ng) in zip(eager["track_iters_per_frame"], graph["track_iters_per_frame"]):
-        assert i == j and abs(ne - ng) <= max(3, ne / 3) and ng < CFG["tracking_itr_num"], (i, ne, ng)
-    for (Re, Te), (Rg, Tg) in zip(eager["poses"], graph["poses"]):
-        assert (Re - Rg).abs().max() < 2e-4 and (Te - Tg).abs().max() < 2e-4
-    for ce, cg in zip(eager["camera_centers"], graph["camera_centers"]):
-        assert (ce - cg).norm() < 2e-4
+    per-iteration `if converged: break` (/root/reference/utils/slam_tracker.py:138-188).  Same map, same frame, same
+    start pose for both, so the only difference left is the summation order of the blend backward's float atomics:
+    poses agree to 1e-5 and the loops leave after the same number of iterations (+-2: the exit test compares an Adam
+    step that hovers around 1e-4 with 1e-4)."""
+    import copy
+    from monogs_amd import fused_losses
+    from monogs_amd.gaussian_map import GaussianMap
+    from monogs_amd.mapping import WindowMapper, render_map
+    from monogs_amd.pose_optim import PoseAdam
+    from monogs_amd.slam_harness import TrackingGraph, Viewpoint, make_sequence
+    dev = "cuda:0"
+    frames, intr = make_sequence(3, "fr3_office", n_gaussians=30000, device=dev)
+    bg = torch.zeros(3, device=dev)
+    gmap = GaussianMap(dev)
+    frames[0].update_RT(frames[0].R_gt.clone(), frames[0].T_gt.clone())
+    gmap.extend_from_frame(frames[0], intr, downsample=8, init=True, point_size=1.0)
+    mapper = WindowMapper(gmap, intr, bg, window_size=8)
+    mapper.map_surgery = False                      # (the mapping thresholds would prune this 80-iteration-old map)
+    mapper.optimize_map([frames[0]], iters=80, init=True)                                            # one map for both loops
+
+    def start(i):                     # frame i, starting from the previous frame's true pose (as the tracker does)
+        f = frames[i]
+        vp = Viewpoint(f.frame_idx, f.rgb, f.depth, dev, gt_R=f.R_gt, gt_T=f.T_gt)
+        vp.update_RT(frames[i - 1].R_gt.clone(), frames[i - 1].T_gt.clone())
+        return vp
+
+    for i in (1, 2):
+        # ---- eager: render -> get_loss_tracking -> backward -> Adam step + update_pose, leave when converged
+        ve = start(i)
+        opt = PoseAdam(ve, 0.003, 0.001, 0.01)
+        n_eager = 100
+        for it in range(100):
+            pkg = render_map(ve, intr, gmap, bg)
+            opt.zero_grad()
+            fused_losses.get_loss_tracking(pkg["render"], pkg["depth"], pkg["opacity"], ve).backward()
+            with torch.no_grad():
+                if opt.step_and_retract():
+                    n_eager = it + 1
+                    break
+        for p in gmap.params():
+            p.grad = None
+        # ---- hipGraph: the same iteration captured once, replayed until the sticky device flag rises
+        vg = start(i)
+        tg = TrackingGraph(vg, intr, gmap, bg)
+        n_graph = tg.track(vg, 100)
+        tg.close()
+        assert 1 < n_eager < 100 and abs(n_eager - n_graph) <= 2, (i, n_eager, n_graph)
+        assert (ve.R - vg.R).abs().max() < 1e-5 and (ve.T - vg.T).abs().max() < 1e-5, (i, (ve.R - vg.R).abs().max())
+        err0 = (-(frames[i - 1].R_gt.t() @ frames[i - 1].T_gt) + (frames[i].R_gt.t() @ frames[i].T_gt)).norm()
+        err1 = (-(vg.R.t() @ vg.T) + (frames[i].R_gt.t() @ frames[i].T_gt)).norm()
+        assert err1 < 0.5 * err0, (i, float(err0), float(err1))
 
 
 def test_mapping_reduces_its_loss(runs):

@@ -37,7 +37,8 @@ constexpr int RS_ITEMS = 16;                       // pairs per thread for large
 constexpr int RS_ITEMS_MID = 8;
 constexpr int RS_ITEMS_SMALL = 4;                  // small sorts are latency-bound: 1024-pair tiles rank 4x faster
 // Measured on MI355X (depth sort of P keys): 40 k: 72 us (16) -> 50 us (4); 400 k: 122 us (32) / 83 us (8);
-// 400 k: 108 us (4); 2 M: 158 us (16) / 208 us (8) / 152 us (32).  A few hundred tiles is the sweet spot between the per-tile
+// 400 k: 108 us (4); 2 M: 158 us (16) / 208 us (8) / 152 us (32).  Pre-scanned path, round 2 (C5): 16 -> 8 items leaves the
+// depth sort at 0.136 ms and takes the tile sort from 0.094 to 0.105 ms; 32 items: 0.168 / 0.116 ms.  A few hundred tiles is the sweet spot between the per-tile
 // ranking latency and the length of the look-back chain.
 static inline int rs_items(uint64_t n) {
     return n <= 192ull * 1024 ? RS_ITEMS_SMALL : (n <= 1024ull * 1024 ? RS_ITEMS_MID : RS_ITEMS);

@@ -298,7 +298,8 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 //  instructions, but the batched atomics (3 gradient lines per instruction, or 3 instructions back to back) were no
 //  longer hidden: 0.60 ms against 0.51 ms at C5, 0.48 ms with the atomics removed.  Also measured: two survivors per
 //  loop trip (independent fetch / alpha / reduction streams interleaved for ILP): 0.536 vs 0.508 ms at C5, 85.9 vs
-//  86.9 us at 100 k / VGA -- the waves are not bound by their dependent chains.  DESIGN.md section 4.)
+//  86.9 us at 100 k / VGA -- the waves are not bound by their dependent chains.  Re-measured: stopping the row butterfly
+//  one step early and handing the atomic unit two lanes per value: 0.523 vs 0.506 ms.  DESIGN.md section 4.)
 template <bool POSE_ONLY>
 __global__ void __launch_bounds__(256) blend_backward_kernel(BlendArgs a, int ntiles,
                                                              const float* __restrict__ final_T,

@@ -259,7 +259,7 @@ def main():
     bucket = GradBucket(params) if (distributed and world > 1) else None
     state = {}
 
-    def step(stats=False):
+    def step(stats=False, reduce=True):
         for p in params:
             p.grad = None
         theta.grad = rho.grad = None
@@ -270,7 +270,7 @@ def main():
         if stats:
             state["walk"] = _rast.debug_blend_stats(color)
         torch.autograd.backward([color, depth], [g_color, g_depth])
-        if bucket is not None:
+        if bucket is not None and reduce:
             bucket.pack()
             bucket.all_reduce()
             bucket.unpack()
@@ -314,7 +314,7 @@ def main():
             step()
         torch.cuda.synchronize()
     if rank == 0:
-        step(stats=True)                     # (un-timed) what the backward walks: survivors, active survivors, pairs
+        step(stats=True, reduce=False)       # (un-timed, rank 0 only: no collective) what the backward walks
         walk = state.get("walk")
         fw = [d for d in sink if d["kind"] == "forward"]
         bw = [d for d in sink if d["kind"] == "backward"]

@@ -204,12 +204,6 @@ int launch_blend_forward(const mgs_camera& cam, const GeometryState& g, const Bi
 // backward: the same walk, back to front, from the pixel's last contributor
 // =================================================================================================
 
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_add(float v) {
-    const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true);
-    return v + __int_as_float(moved);
-}
-
 // ---- packed reduction of 10 per-lane values over the 64 lanes --------------------------------
 // stage 1: v_permlane32_swap pairs (x, y): lanes 0-31 then hold x[l]+x[l+32], lanes 32-63 y[l-32]+y[l]
 // stage 2: v_permlane16_swap pairs those: each 16-lane row then holds 16 partials of ONE value
@@ -237,10 +231,6 @@ __device__ __forceinline__ float row_sum_all(float v) {
     v = swz_add<4>(v);
     v = swz_add<8>(v);
     return v;
-}
-template <int CTRL>
-__device__ __forceinline__ float dpp_mov(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
 }
 // Where reduce10 leaves value k (k = gradient slot G_SX..G_DDEPTH):
 //   lane 15: a0   lane 31: a2   lane 47: a1   lane 63: a3      (register c0, row sums in every lane)

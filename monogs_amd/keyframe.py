@@ -49,9 +49,16 @@ def densification_mask(gt_depth: torch.Tensor, render_depth: Optional[torch.Tens
 def create_viewpoint_pcd(viewpoint, cam_intrinsics, render_depth=None, render_opacity=None, init=False,
                          isotropic=True, random_indices: Optional[torch.Tensor] = None,
                          generator: Optional[torch.Generator] = None, downsample_factor: Optional[int] = None,
-                         point_size: float = 0.01, point_size_max: float = 0.05):
+                         point_size: float = 0.01, point_size_max: float = 0.05,
+                         knn_against: Optional[torch.Tensor] = None):
     """``downsample_factor`` / ``point_size`` / ``point_size_max`` default to the values hard-coded in the reference
-    (32 or 64, 0.01, 0.05: gaussian_model.py:166-178)."""
+    (32 or 64, 0.01, 0.05: gaussian_model.py:166-178).
+
+    ``knn_against`` (OPT-IN, changes results relative to the reference): the positions ``[M,3]`` of the Gaussians already in
+    the map.  The reference sizes a new Gaussian from its 3 nearest neighbours among the NEW points only and leaves
+    "TODO: should compute against all existing gaussians" (gaussian_model.py:293); with this argument the neighbours are
+    searched in new + existing points (one Morton-box kNN over the concatenated cloud: ~3 ms at 2 M points), so a point
+    that lands next to mapped geometry gets a scale that fits it instead of the spacing of the sparse new sample."""
     lib = _lib.load()
     rgb = viewpoint.rgb.to(torch.float32).contiguous()
     depth = viewpoint.depth.to(torch.float32).contiguous()
@@ -84,7 +91,12 @@ def create_viewpoint_pcd(viewpoint, cam_intrinsics, render_depth=None, render_op
         _lib.check(lib.mgs_backproject(N, W, H, p(sel), p(rgb), p(depth), p(seg32), p(ea), p(eb), fx, fy, cx, cy, p(R), p(T),
                                        p(pts), p(feat), p(ids), _stream()), "mgs_backproject")
     if N > 0:
-        dist2 = torch.clamp_min(distCUDA2(pts), 1e-7) * point_size
+        if knn_against is not None and knn_against.shape[0] > 0:
+            cloud = torch.cat([pts, knn_against.detach().to(pts.dtype).reshape(-1, 3)], 0).contiguous()
+            d2 = distCUDA2(cloud)[:N]
+        else:
+            d2 = distCUDA2(pts)
+        dist2 = torch.clamp_min(d2, 1e-7) * point_size
         scales = torch.log(torch.sqrt(dist2))[:, None]
     else:
         scales = torch.empty(0, 1, device=dev)

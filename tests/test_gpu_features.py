@@ -500,3 +500,44 @@ def test_isotropic_scales_match_repeat(native_lib):
     assert ga[1].shape == (8000, 1)
     for a, b in zip(ga, gb):
         assert (a - b).norm() <= 2e-5 * b.norm() + 1e-12
+
+
+def test_backward_walk_statistics_are_consistent(native_lib):
+    """mgs_debug_blend_stats (the counting twin of the blend backward that feeds bench.py's `roofline.valu`): its counts obey
+    the structure of the walk, and the number of active (pixel, instance) pairs equals what the ORACLE blends -- every
+    pair the forward blended is replayed by the backward, no more, no less."""
+    from monogs_amd.rasterizer import GaussianRasterizer, debug_blend_stats
+    sc = make_scene(6000, "fr3_office", seed=12, mean_radius_px=8.0)
+    m = sc.means3D.to(DEV).clone().requires_grad_(True)
+    out = GaussianRasterizer(_hip_st(sc))(means3D=m, means2D=torch.zeros_like(m), opacities=sc.opacities.to(DEV),
+                                          colors_precomp=sc.colors.to(DEV), scales=sc.scales.to(DEV),
+                                          rotations=sc.rotations.to(DEV))
+    st = debug_blend_stats(out[0])
+    assert st["steps"] > 0 and 0 < st["active_survivors"] <= st["survivors"]
+    assert st["active_survivors"] <= st["active_pairs"] <= 64 * st["active_survivors"]
+    assert st["active_le2"] <= st["active_le4"] <= st["active_le8"] <= st["active_survivors"]
+    assert st["inactive_by_depth_order"] <= st["survivors"] - st["active_survivors"]
+    # oracle: pairs with a non-zero blend weight = sum over instances of the pixels they were blended into
+    o = rasterize(sc.means3D, None, sc.opacities, scene_settings(sc, OracleSettings), colors_precomp=sc.colors,
+                  scales=sc.scales.repeat(1, 3), rotations=sc.rotations, want_ambiguous=True)
+    geom, pl, rg = o.aux["geom"], o.aux["point_list"], o.aux["ranges"]
+    H, W = 480, 640
+    pairs = 0
+    n_contrib = o.aux["n_contrib"][0]
+    for t in range(rg.shape[0]):
+        s, e = int(rg[t, 0]), int(rg[t, 1])
+        if e <= s:
+            continue
+        tx, ty = t % 40, t // 40
+        ys, xs = torch.meshgrid(torch.arange(ty * 16, min(ty * 16 + 16, H)), torch.arange(tx * 16, min(tx * 16 + 16, W)), indexing="ij")
+        px, py = xs.reshape(-1).float(), ys.reshape(-1).float()
+        ids = pl[s:e]
+        xy, con, op = geom["xy"][ids], geom["conic"][ids], geom["opacity"][ids]
+        dx, dy = xy[None, :, 0] - px[:, None], xy[None, :, 1] - py[:, None]
+        power = -0.5 * (con[None, :, 0] * dx * dx + con[None, :, 2] * dy * dy) - con[None, :, 1] * dx * dy
+        alpha = torch.clamp_max(op[None, :] * torch.exp(power), 0.99)
+        last = n_contrib[ys.reshape(-1), xs.reshape(-1)]
+        k = torch.arange(1, e - s + 1)[None, :]
+        pairs += int(((k <= last[:, None]) & ~(power > 0) & ~(alpha < 1.0 / 255.0)).sum())
+    amb = int(o.aux["ambiguous"].sum())
+    assert abs(st["active_pairs"] - pairs) <= 64 * amb + 8, (st["active_pairs"], pairs, amb)

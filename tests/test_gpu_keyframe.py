@@ -87,3 +87,27 @@ def test_create_viewpoint_pcd_device_subset(native_lib):
     g2 = torch.Generator(device=DEV).manual_seed(1)
     again = create_viewpoint_pcd(vp, intr, rdepth, ropac, init=False, generator=g2)[0]
     assert torch.equal(pts, again)                                  # deterministic given the generator
+
+
+def test_knn_against_the_whole_map_is_opt_in_and_exact(native_lib):
+    """`knn_against=map_xyz` (the reference's own TODO, gaussian_model.py:293): the scale of a new Gaussian comes from its
+    3 nearest neighbours among new AND existing points -- checked against the cKDTree oracle on the concatenated cloud;
+    without the argument the result is the reference's (neighbours among the new points only)."""
+    from monogs_amd.keyframe import create_viewpoint_pcd
+    from oracle import dist2_knn
+    vp, intr, rdepth, ropac = _frame(3)
+    g = torch.Generator().manual_seed(9)
+    pick = torch.randperm(int((vp.depth >= 1e-3).sum()), generator=g)       # a permutation of the CANDIDATE pixels
+    ref = create_viewpoint_pcd(vp, intr, init=True, random_indices=pick)
+    pts = ref[0]
+    # an existing map: points scattered right around the new ones (so that the nearest neighbours change) + far clutter
+    near = pts[::3] + 0.002 * torch.randn(pts[::3].shape, generator=g).to(DEV)
+    far = (torch.rand(5000, 3, generator=g) * 40 - 20).to(DEV)
+    map_xyz = torch.cat([near, far], 0)
+    out = create_viewpoint_pcd(vp, intr, init=True, random_indices=pick, knn_against=map_xyz)
+    assert torch.equal(out[0], pts) and torch.equal(out[1], ref[1])          # positions and colours unchanged
+    ps = torch.clamp_max(0.01 * vp.depth.median(), 0.05).cpu()
+    want = torch.log(torch.sqrt(torch.clamp_min(dist2_knn(torch.cat([pts, map_xyz], 0).cpu())[:pts.shape[0]], 1e-7) * ps))
+    assert torch.allclose(out[2][:, 0].cpu(), want, rtol=1e-5, atol=1e-6)
+    assert (out[2] < ref[2] - 1e-3).float().mean() > 0.2                     # a good share of the scales shrank
+    assert not (out[2] > ref[2] + 1e-5).any()                               # more candidates can only bring neighbours closer

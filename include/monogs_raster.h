@@ -191,6 +191,7 @@ int mgs_dist2_knn(int32_t P, const float* points /* [P,3] */, float* out /* [P] 
  * d_exposure may be the two floats at scratch + MGS_LOSS_SCRATCH_DAB, which the forward leaves zeroed: the first
  * backward of a forward can accumulate there without a separate clear (one launch less). */
 #define MGS_LOSS_SCRATCH_DAB 10
+#define MGS_LOSS_SCRATCH_LOSS 12
 size_t mgs_loss_scratch_bytes(void);
 int mgs_loss_forward(int32_t width, int32_t height, int32_t tracking, int32_t init, float lambda_rgb,
                      const float* render, const float* depth, const float* opacity, const float* gt_rgb,
@@ -202,6 +203,15 @@ int mgs_loss_backward(int32_t width, int32_t height, int32_t tracking, int32_t i
                       const float* gt_depth, const uint8_t* mask, const uint8_t* grad_mask,
                       const float* exposure_a, const float* exposure_b, const float* scratch,
                       const float* grad_out, float* d_render, float* d_depth, float* d_exposure, void* stream);
+/* Loss value AND gradients (for grad_out = 1) in two launches, for loops that drive the rasteriser's backward themselves
+ * (torch.autograd.backward([color, depth], [d_render, d_depth])) instead of building an autograd node for the scalar:
+ * no finalize kernel, no ones-fill.  Afterwards scratch[MGS_LOSS_SCRATCH_LOSS] holds the loss value and
+ * scratch[MGS_LOSS_SCRATCH_DAB .. +1] hold dL/d(exposure_a), dL/d(exposure_b) (unless `init`). */
+int mgs_loss_grads(int32_t width, int32_t height, int32_t tracking, int32_t init, float lambda_rgb,
+                   const float* render, const float* depth, const float* opacity, const float* gt_rgb,
+                   const float* gt_depth, const uint8_t* mask, const uint8_t* grad_mask,
+                   const float* exposure_a, const float* exposure_b, float* scratch, float* d_render, float* d_depth,
+                   void* stream);
 
 /* ---- Fused pose update (caller-side widening) -------------------------------
  * torch.optim.Adam.step() on (cam_rot_delta lr_rot, cam_trans_delta lr_trans, exposure_a/b lr_exposure)

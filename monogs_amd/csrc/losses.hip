@@ -21,7 +21,7 @@ namespace mgs {
 constexpr int LS_THREADS = 256;
 constexpr int LS_MAX_BLOCKS = 256;      // forward reduction: two stages, no atomics (64 workgroups were latency-bound: 26 us at VGA)
 // scratch: 16 floats of results followed by LS_MAX_BLOCKS x 8 floats of per-workgroup partial sums
-enum : int { LP_L1_RGB = 6, LP_L1_D = 7, LP_SCALE_RGB = 8, LP_SCALE_D = 9, LP_DAB = 10, LP_N = 16, LP_PART = 8 };
+enum : int { LP_L1_RGB = 6, LP_L1_D = 7, LP_SCALE_RGB = 8, LP_SCALE_D = 9, LP_DAB = 10, LP_LOSS = 12, LP_N = 16, LP_PART = 8 };
 // scratch[LP_DAB .. LP_DAB+1]: left ZERO by the forward; a backward may accumulate d(exposure_a), d(exposure_b) there
 // (d_exposure == scratch + LP_DAB), which saves the launch that clears a separate buffer
 
@@ -44,50 +44,95 @@ __device__ __forceinline__ float block_sum(float v, float* smem) {
 
 __device__ __forceinline__ float sgn(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }
 
-__global__ void __launch_bounds__(LS_THREADS) loss_forward_kernel(LossArgs a, float* __restrict__ part) {
+// per-pixel terms of the forward sums (shared by the scalar and the 4-pixel paths)
+struct FwdAcc { float s_rgb, c_rgb, s_d, c_d, s_op; };
+__device__ __forceinline__ void fwd_pixel(const LossArgs& a, float ea, float eb, float gd, bool mask, bool gmask, float op,
+                                          float r0, float r1, float r2, float g0, float g1, float g2, float d, FwdAcc& acc) {
+    bool m_rgb = mask, m_d = gd > 0.f;
+    if (a.tracking) {
+        const bool opaque = op > 0.99f;
+        acc.s_op += op;
+        m_rgb = m_rgb && gmask && opaque;
+        m_d = m_d && opaque;
+    }
+    if (m_rgb) {
+        acc.s_rgb += fabsf(ea * r0 + eb - g0) + fabsf(ea * r1 + eb - g1) + fabsf(ea * r2 + eb - g2);
+        acc.c_rgb += 3.f;
+    }
+    if (m_d) {
+        acc.s_d += fabsf(d - gd);
+        acc.c_d += 1.f;
+    }
+}
+
+// VEC4: every image is read four pixels at a time (16-byte loads; needs H*W % 4 == 0 and 16-byte-aligned images): a
+// thread then has all its loads in flight at once instead of ~11 dependent-latency scalar loads per pixel.
+template <bool VEC4>
+__global__ void __launch_bounds__(LS_THREADS) loss_forward_kernel(LossArgs a, float* __restrict__ part, int zero_dab) {
     __shared__ float smem[4];
+    if (zero_dab && blockIdx.x == 0 && threadIdx.x < 2) part[LP_DAB + threadIdx.x] = 0.f;   // fused mode: no finalize kernel to do it
     const size_t HW = (size_t)a.W * a.H;
     const float ea = a.init ? 1.f : __expf(a.exp_a[0]), eb = a.init ? 0.f : a.exp_b[0];
-    float s_rgb = 0.f, c_rgb = 0.f, s_d = 0.f, c_d = 0.f, s_op = 0.f;
-    for (size_t p = (size_t)blockIdx.x * LS_THREADS + threadIdx.x; p < HW; p += (size_t)gridDim.x * LS_THREADS) {
-        const float gd = a.gt_depth[p];
-        bool m_rgb = a.mask ? a.mask[p] != 0 : true;
-        bool m_d = gd > 0.f;
-        if (a.tracking) {
-            const float op = a.opacity[p];
-            const bool opaque = op > 0.99f;
-            s_op += op;
-            m_rgb = m_rgb && (a.grad_mask[p] != 0) && opaque;
-            m_d = m_d && opaque;
+    FwdAcc acc = {0.f, 0.f, 0.f, 0.f, 0.f};
+    const size_t stride = (size_t)gridDim.x * LS_THREADS;
+    if (VEC4) {
+        const size_t NQ = HW / 4;
+        const float4 *R0 = (const float4*)a.render, *R1 = (const float4*)(a.render + HW), *R2 = (const float4*)(a.render + 2 * HW);
+        const float4 *G0 = (const float4*)a.gt_rgb, *G1 = (const float4*)(a.gt_rgb + HW), *G2 = (const float4*)(a.gt_rgb + 2 * HW);
+        for (size_t q = (size_t)blockIdx.x * LS_THREADS + threadIdx.x; q < NQ; q += stride) {
+            const float4 gd = ((const float4*)a.gt_depth)[q], d = ((const float4*)a.depth)[q];
+            const float4 r0 = R0[q], r1 = R1[q], r2 = R2[q], g0 = G0[q], g1 = G1[q], g2 = G2[q];
+            const uchar4 mk = a.mask ? ((const uchar4*)a.mask)[q] : make_uchar4(1, 1, 1, 1);
+            const uchar4 gm = a.tracking ? ((const uchar4*)a.grad_mask)[q] : make_uchar4(1, 1, 1, 1);
+            const float4 op = a.tracking ? ((const float4*)a.opacity)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+            fwd_pixel(a, ea, eb, gd.x, mk.x != 0, gm.x != 0, op.x, r0.x, r1.x, r2.x, g0.x, g1.x, g2.x, d.x, acc);
+            fwd_pixel(a, ea, eb, gd.y, mk.y != 0, gm.y != 0, op.y, r0.y, r1.y, r2.y, g0.y, g1.y, g2.y, d.y, acc);
+            fwd_pixel(a, ea, eb, gd.z, mk.z != 0, gm.z != 0, op.z, r0.z, r1.z, r2.z, g0.z, g1.z, g2.z, d.z, acc);
+            fwd_pixel(a, ea, eb, gd.w, mk.w != 0, gm.w != 0, op.w, r0.w, r1.w, r2.w, g0.w, g1.w, g2.w, d.w, acc);
         }
-        if (m_rgb) {
-            const float r0 = ea * a.render[p] + eb - a.gt_rgb[p];
-            const float r1 = ea * a.render[HW + p] + eb - a.gt_rgb[HW + p];
-            const float r2 = ea * a.render[2 * HW + p] + eb - a.gt_rgb[2 * HW + p];
-            s_rgb += fabsf(r0) + fabsf(r1) + fabsf(r2);
-            c_rgb += 3.f;
-        }
-        if (m_d) {
-            s_d += fabsf(a.depth[p] - gd);
-            c_d += 1.f;
-        }
+    } else {
+        for (size_t p = (size_t)blockIdx.x * LS_THREADS + threadIdx.x; p < HW; p += stride)
+            fwd_pixel(a, ea, eb, a.gt_depth[p], a.mask ? a.mask[p] != 0 : true, a.tracking ? a.grad_mask[p] != 0 : true,
+                      a.tracking ? a.opacity[p] : 0.f, a.render[p], a.render[HW + p], a.render[2 * HW + p], a.gt_rgb[p],
+                      a.gt_rgb[HW + p], a.gt_rgb[2 * HW + p], a.depth[p], acc);
     }
-    s_rgb = block_sum(s_rgb, smem);
-    c_rgb = block_sum(c_rgb, smem);
-    s_d = block_sum(s_d, smem);
-    c_d = block_sum(c_d, smem);
-    s_op = block_sum(s_op, smem);
+    const float s_rgb = block_sum(acc.s_rgb, smem), c_rgb = block_sum(acc.c_rgb, smem);
+    const float s_d = block_sum(acc.s_d, smem), c_d = block_sum(acc.c_d, smem), s_op = block_sum(acc.s_op, smem);
     if (threadIdx.x == 0) {
         float* o = part + LP_N + (size_t)blockIdx.x * LP_PART;
         o[0] = s_rgb; o[1] = c_rgb; o[2] = s_d; o[3] = c_d; o[4] = s_op;
     }
 }
 
-// one wave: sum the per-workgroup partials in a fixed order (bitwise reproducible) and finish the scalar
-__global__ void loss_finalize_kernel(LossArgs a, int nblocks, float* __restrict__ part, float* __restrict__ loss_out) {
-    const int lane = threadIdx.x;
-    float v[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int b = lane; b < nblocks; b += WAVE) {          // fixed order: lane l adds blocks l, l+64, ...
+struct LossScalars { float l1_rgb, l1_d, scale_rgb, scale_d, loss; };
+
+// the scalar part of the loss from the five sums (see the formulas at the top of the file)
+__device__ __forceinline__ LossScalars loss_scalars(const LossArgs& a, const float v[5]) {
+    const size_t HW = (size_t)a.W * a.H;
+    const float S_rgb = v[0], C_rgb = v[1], S_d = v[2], C_d = v[3], S_op = v[4];
+    LossScalars r;
+    if (a.tracking) {
+        const float mean_op = S_op / (float)HW;
+        r.l1_rgb = mean_op * (S_rgb / (3.f * (float)HW));
+        r.l1_d = C_d > 0.f ? S_d / C_d : 0.f;
+        r.scale_rgb = 0.5f * mean_op / (3.f * (float)HW);
+        r.scale_d = C_d > 0.f ? 1.f / C_d : 0.f;
+        r.loss = 0.5f * r.l1_rgb + r.l1_d;
+    } else {
+        r.l1_rgb = S_rgb / C_rgb;                       // NaN when the mask is empty, like torch's mean of nothing
+        r.l1_d = S_d / C_d;
+        r.scale_rgb = a.lambda_rgb / C_rgb;
+        r.scale_d = (1.f - a.lambda_rgb) / C_d;
+        r.loss = a.lambda_rgb * r.l1_rgb + (1.f - a.lambda_rgb) * r.l1_d;
+    }
+    return r;
+}
+
+// one wave: sum the per-workgroup partials in a fixed order (lane l adds blocks l, l+64, ...: bitwise reproducible)
+__device__ __forceinline__ void sum_partials(const float* __restrict__ part, int nblocks, int lane, float v[5]) {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) v[k] = 0.f;
+    for (int b = lane; b < nblocks; b += WAVE) {
         const float* o = part + LP_N + (size_t)b * LP_PART;
 #pragma unroll
         for (int k = 0; k < 5; ++k) v[k] += o[k];
@@ -96,66 +141,104 @@ __global__ void loss_finalize_kernel(LossArgs a, int nblocks, float* __restrict_
     for (int k = 0; k < 5; ++k)
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_xor(v[k], o, 64);
+}
+
+__global__ void loss_finalize_kernel(LossArgs a, int nblocks, float* __restrict__ part, float* __restrict__ loss_out) {
+    const int lane = threadIdx.x;
+    float v[5];
+    sum_partials(part, nblocks, lane, v);
     if (lane == 0) {
-        const size_t HW = (size_t)a.W * a.H;
-        const float S_rgb = v[0], C_rgb = v[1], S_d = v[2], C_d = v[3], S_op = v[4];
-        float l1_rgb, l1_d, scale_rgb, scale_d, loss;
-        if (a.tracking) {
-            const float mean_op = S_op / (float)HW;
-            l1_rgb = mean_op * (S_rgb / (3.f * (float)HW));
-            l1_d = C_d > 0.f ? S_d / C_d : 0.f;
-            scale_rgb = 0.5f * mean_op / (3.f * (float)HW);
-            scale_d = C_d > 0.f ? 1.f / C_d : 0.f;
-            loss = 0.5f * l1_rgb + l1_d;
-        } else {
-            l1_rgb = S_rgb / C_rgb;                       // NaN when the mask is empty, like torch's mean of nothing
-            l1_d = S_d / C_d;
-            scale_rgb = a.lambda_rgb / C_rgb;
-            scale_d = (1.f - a.lambda_rgb) / C_d;
-            loss = a.lambda_rgb * l1_rgb + (1.f - a.lambda_rgb) * l1_d;
-        }
-        part[LP_L1_RGB] = l1_rgb;
-        part[LP_L1_D] = l1_d;
-        part[LP_SCALE_RGB] = scale_rgb;
-        part[LP_SCALE_D] = scale_d;
+        const LossScalars r = loss_scalars(a, v);
+        part[LP_L1_RGB] = r.l1_rgb;
+        part[LP_L1_D] = r.l1_d;
+        part[LP_SCALE_RGB] = r.scale_rgb;
+        part[LP_SCALE_D] = r.scale_d;
         part[LP_DAB] = 0.f;
         part[LP_DAB + 1] = 0.f;
-        loss_out[0] = loss;
+        loss_out[0] = r.loss;
     }
 }
 
-__global__ void __launch_bounds__(LS_THREADS) loss_backward_kernel(LossArgs a, const float* __restrict__ part,
+// fwd_blocks > 0: "fused" mode -- no finalize kernel ran: every workgroup adds the forward's partial sums up itself (its
+// first wave, fixed order, <= 8 KB out of L2) and workgroup 0 also stores the loss value for whoever wants to log it.
+template <bool VEC4>
+__global__ void __launch_bounds__(LS_THREADS) loss_backward_kernel(LossArgs a, float* __restrict__ part, int fwd_blocks,
                                                                    const float* __restrict__ grad_out,
                                                                    float* __restrict__ d_render,
                                                                    float* __restrict__ d_depth,
                                                                    float* __restrict__ d_ab) {
     __shared__ float smem[4];
+    __shared__ float s_scale[2];
     const size_t HW = (size_t)a.W * a.H;
     const float go = grad_out ? grad_out[0] : 1.f;
     const float ea = a.init ? 1.f : __expf(a.exp_a[0]), eb = a.init ? 0.f : a.exp_b[0];
-    const float k_rgb = go * part[LP_SCALE_RGB], k_d = go * part[LP_SCALE_D];
+    if (fwd_blocks > 0) {
+        if (threadIdx.x < WAVE) {
+            float v[5];
+            sum_partials(part, fwd_blocks, (int)threadIdx.x, v);
+            if (threadIdx.x == 0) {
+                const LossScalars r = loss_scalars(a, v);
+                s_scale[0] = r.scale_rgb; s_scale[1] = r.scale_d;
+                if (blockIdx.x == 0) {
+                    part[LP_L1_RGB] = r.l1_rgb; part[LP_L1_D] = r.l1_d; part[LP_SCALE_RGB] = r.scale_rgb;
+                    part[LP_SCALE_D] = r.scale_d; part[LP_LOSS] = r.loss;
+                }
+            }
+        }
+        __syncthreads();
+    } else if (threadIdx.x == 0) {
+        s_scale[0] = part[LP_SCALE_RGB]; s_scale[1] = part[LP_SCALE_D];
+    }
+    if (fwd_blocks <= 0) __syncthreads();
+    const float k_rgb = go * s_scale[0], k_d = go * s_scale[1];
     float g_a = 0.f, g_b = 0.f;
-    for (size_t p = (size_t)blockIdx.x * LS_THREADS + threadIdx.x; p < HW; p += (size_t)gridDim.x * LS_THREADS) {
-        const float gd = a.gt_depth[p];
-        bool m_rgb = a.mask ? a.mask[p] != 0 : true;
-        bool m_d = gd > 0.f;
+    const size_t stride = (size_t)gridDim.x * LS_THREADS;
+    // one pixel: returns the three colour gradients and the depth gradient, accumulates the exposure gradients
+    auto pixel = [&](float gd, bool mask, bool gmask, float op, float x0, float x1, float x2, float t0, float t1, float t2,
+                     float d, float& o0, float& o1, float& o2, float& od) {
+        bool m_rgb = mask, m_d = gd > 0.f;
         if (a.tracking) {
-            const bool opaque = a.opacity[p] > 0.99f;
-            m_rgb = m_rgb && (a.grad_mask[p] != 0) && opaque;
+            const bool opaque = op > 0.99f;
+            m_rgb = m_rgb && gmask && opaque;
             m_d = m_d && opaque;
         }
-        float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+        o0 = o1 = o2 = 0.f;
         if (m_rgb) {
-            const float x0 = a.render[p], x1 = a.render[HW + p], x2 = a.render[2 * HW + p];
-            const float s0 = sgn(ea * x0 + eb - a.gt_rgb[p]);
-            const float s1 = sgn(ea * x1 + eb - a.gt_rgb[HW + p]);
-            const float s2 = sgn(ea * x2 + eb - a.gt_rgb[2 * HW + p]);
+            const float s0 = sgn(ea * x0 + eb - t0), s1 = sgn(ea * x1 + eb - t1), s2 = sgn(ea * x2 + eb - t2);
             o0 = k_rgb * ea * s0; o1 = k_rgb * ea * s1; o2 = k_rgb * ea * s2;
             g_a += k_rgb * ea * (s0 * x0 + s1 * x1 + s2 * x2);      // d/da of exp(a) x + b
             g_b += k_rgb * (s0 + s1 + s2);
         }
-        d_render[p] = o0; d_render[HW + p] = o1; d_render[2 * HW + p] = o2;
-        d_depth[p] = m_d ? k_d * sgn(a.depth[p] - gd) : 0.f;
+        od = m_d ? k_d * sgn(d - gd) : 0.f;
+    };
+    if (VEC4) {
+        const size_t NQ = HW / 4;
+        const float4 *R0 = (const float4*)a.render, *R1 = (const float4*)(a.render + HW), *R2 = (const float4*)(a.render + 2 * HW);
+        const float4 *G0 = (const float4*)a.gt_rgb, *G1 = (const float4*)(a.gt_rgb + HW), *G2 = (const float4*)(a.gt_rgb + 2 * HW);
+        float4 *O0 = (float4*)d_render, *O1 = (float4*)(d_render + HW), *O2 = (float4*)(d_render + 2 * HW);
+        for (size_t q = (size_t)blockIdx.x * LS_THREADS + threadIdx.x; q < NQ; q += stride) {
+            const float4 gd = ((const float4*)a.gt_depth)[q], d = ((const float4*)a.depth)[q];
+            const float4 r0 = R0[q], r1 = R1[q], r2 = R2[q], t0 = G0[q], t1 = G1[q], t2 = G2[q];
+            const uchar4 mk = a.mask ? ((const uchar4*)a.mask)[q] : make_uchar4(1, 1, 1, 1);
+            const uchar4 gm = a.tracking ? ((const uchar4*)a.grad_mask)[q] : make_uchar4(1, 1, 1, 1);
+            const float4 op = a.tracking ? ((const float4*)a.opacity)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 o0, o1, o2, od;
+            pixel(gd.x, mk.x != 0, gm.x != 0, op.x, r0.x, r1.x, r2.x, t0.x, t1.x, t2.x, d.x, o0.x, o1.x, o2.x, od.x);
+            pixel(gd.y, mk.y != 0, gm.y != 0, op.y, r0.y, r1.y, r2.y, t0.y, t1.y, t2.y, d.y, o0.y, o1.y, o2.y, od.y);
+            pixel(gd.z, mk.z != 0, gm.z != 0, op.z, r0.z, r1.z, r2.z, t0.z, t1.z, t2.z, d.z, o0.z, o1.z, o2.z, od.z);
+            pixel(gd.w, mk.w != 0, gm.w != 0, op.w, r0.w, r1.w, r2.w, t0.w, t1.w, t2.w, d.w, o0.w, o1.w, o2.w, od.w);
+            O0[q] = o0; O1[q] = o1; O2[q] = o2;
+            ((float4*)d_depth)[q] = od;
+        }
+    } else {
+        for (size_t p = (size_t)blockIdx.x * LS_THREADS + threadIdx.x; p < HW; p += stride) {
+            float o0, o1, o2, od;
+            pixel(a.gt_depth[p], a.mask ? a.mask[p] != 0 : true, a.tracking ? a.grad_mask[p] != 0 : true,
+                  a.tracking ? a.opacity[p] : 0.f, a.render[p], a.render[HW + p], a.render[2 * HW + p], a.gt_rgb[p],
+                  a.gt_rgb[HW + p], a.gt_rgb[2 * HW + p], a.depth[p], o0, o1, o2, od);
+            d_render[p] = o0; d_render[HW + p] = o1; d_render[2 * HW + p] = o2;
+            d_depth[p] = od;
+        }
     }
     if (d_ab && !a.init) {
         g_a = block_sum(g_a, smem);
@@ -167,10 +250,17 @@ __global__ void __launch_bounds__(LS_THREADS) loss_backward_kernel(LossArgs a, c
     }
 }
 
-static int loss_grid(int W, int H) {
+// four pixels per thread on the vector path
+static bool loss_vec4(const LossArgs& a, const float* d_render, const float* d_depth) {
+    const size_t HW = (size_t)a.W * a.H;
+    auto al = [](const void* p, size_t n) { return p == nullptr || ((size_t)p % n) == 0; };
+    return HW % 4 == 0 && al(a.render, 16) && al(a.depth, 16) && al(a.opacity, 16) && al(a.gt_rgb, 16) && al(a.gt_depth, 16) &&
+           al(a.mask, 4) && al(a.grad_mask, 4) && al(d_render, 16) && al(d_depth, 16);
+}
+static int loss_grid(int W, int H) {          // ~4 pixels per thread: one quad on the vector path
     const size_t HW = (size_t)W * H;
     size_t nb = (HW + LS_THREADS * 4 - 1) / (LS_THREADS * 4);
-    return (int)(nb < 1 ? 1 : (nb > 1024 ? 1024 : nb));
+    return (int)(nb < 1 ? 1 : (nb > 2048 ? 2048 : nb));
 }
 static int loss_fwd_grid(int W, int H) {
     const int g = loss_grid(W, H);
@@ -179,17 +269,39 @@ static int loss_fwd_grid(int W, int H) {
 
 int launch_loss_forward(const LossArgs& a, float* partials, float* loss_out, hipStream_t s) {
     const int nb = loss_fwd_grid(a.W, a.H);
-    hipLaunchKernelGGL(loss_forward_kernel, dim3(nb), dim3(LS_THREADS), 0, s, a, partials);
+    if (loss_vec4(a, nullptr, nullptr)) hipLaunchKernelGGL(loss_forward_kernel<true>, dim3(nb), dim3(LS_THREADS), 0, s, a, partials, 0);
+    else hipLaunchKernelGGL(loss_forward_kernel<false>, dim3(nb), dim3(LS_THREADS), 0, s, a, partials, 0);
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(WAVE), 0, s, a, nb, partials, loss_out);
     MGS_HIP(hipGetLastError());
     return 0;
 }
 
-int launch_loss_backward(const LossArgs& a, const float* partials, const float* grad_out, float* d_render,
+int launch_loss_backward(const LossArgs& a, float* partials, const float* grad_out, float* d_render,
                          float* d_depth, float* d_ab, hipStream_t s) {
     if (d_ab && d_ab != partials + LP_DAB) MGS_HIP(zero_fill(d_ab, 2 * sizeof(float), s));
-    hipLaunchKernelGGL(loss_backward_kernel, dim3(loss_grid(a.W, a.H)), dim3(LS_THREADS), 0, s, a, partials, grad_out,
-                       d_render, d_depth, d_ab);
+    if (loss_vec4(a, d_render, d_depth))
+        hipLaunchKernelGGL(loss_backward_kernel<true>, dim3(loss_grid(a.W, a.H)), dim3(LS_THREADS), 0, s, a, partials, 0, grad_out,
+                           d_render, d_depth, d_ab);
+    else
+        hipLaunchKernelGGL(loss_backward_kernel<false>, dim3(loss_grid(a.W, a.H)), dim3(LS_THREADS), 0, s, a, partials, 0, grad_out,
+                           d_render, d_depth, d_ab);
+    MGS_HIP(hipGetLastError());
+    return 0;
+}
+
+// value + gradients in TWO launches (no finalize kernel, no autograd node for the scalar, hence no ones-fill either)
+int launch_loss_grads(const LossArgs& a, float* partials, float* d_render, float* d_depth, hipStream_t s) {
+    const int nb = loss_fwd_grid(a.W, a.H);
+    float* d_ab = a.init ? nullptr : partials + LP_DAB;
+    if (loss_vec4(a, d_render, d_depth)) {
+        hipLaunchKernelGGL(loss_forward_kernel<true>, dim3(nb), dim3(LS_THREADS), 0, s, a, partials, 1);
+        hipLaunchKernelGGL(loss_backward_kernel<true>, dim3(loss_grid(a.W, a.H)), dim3(LS_THREADS), 0, s, a, partials, nb, nullptr,
+                           d_render, d_depth, d_ab);
+    } else {
+        hipLaunchKernelGGL(loss_forward_kernel<false>, dim3(nb), dim3(LS_THREADS), 0, s, a, partials, 1);
+        hipLaunchKernelGGL(loss_backward_kernel<false>, dim3(loss_grid(a.W, a.H)), dim3(LS_THREADS), 0, s, a, partials, nb, nullptr,
+                           d_render, d_depth, d_ab);
+    }
     MGS_HIP(hipGetLastError());
     return 0;
 }
@@ -236,7 +348,18 @@ int mgs_loss_backward(int32_t W, int32_t H, int32_t tracking, int32_t init, floa
     if (fill_args(a, W, H, tracking, init, lambda_rgb, render, depth, opacity, gt_rgb, gt_depth, mask, grad_mask,
                   exposure_a, exposure_b)) return 1;
     if (!scratch || !d_render || !d_depth) { set_error("scratch, d_render, d_depth must be non-NULL"); return 1; }
-    return launch_loss_backward(a, scratch, grad_out, d_render, d_depth, d_exposure, (hipStream_t)stream);
+    return launch_loss_backward(a, const_cast<float*>(scratch), grad_out, d_render, d_depth, d_exposure, (hipStream_t)stream);
+}
+
+int mgs_loss_grads(int32_t W, int32_t H, int32_t tracking, int32_t init, float lambda_rgb, const float* render,
+                   const float* depth, const float* opacity, const float* gt_rgb, const float* gt_depth,
+                   const uint8_t* mask, const uint8_t* grad_mask, const float* exposure_a, const float* exposure_b,
+                   float* scratch, float* d_render, float* d_depth, void* stream) {
+    LossArgs a;
+    if (fill_args(a, W, H, tracking, init, lambda_rgb, render, depth, opacity, gt_rgb, gt_depth, mask, grad_mask,
+                  exposure_a, exposure_b)) return 1;
+    if (!scratch || !d_render || !d_depth) { set_error("scratch, d_render, d_depth must be non-NULL"); return 1; }
+    return launch_loss_grads(a, scratch, d_render, d_depth, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -16,6 +16,7 @@ from .rasterizer import _f32, _stream, _device_guard
 
 
 _DAB = 10     # MGS_LOSS_SCRATCH_DAB (include/monogs_raster.h)
+_LOSS = 12    # MGS_LOSS_SCRATCH_LOSS
 
 
 def _u8(t):
@@ -96,3 +97,58 @@ def get_loss_tracking(render_image, render_depth, render_opacity, viewpoint, inv
     return _FusedLoss.apply(render_image, render_depth, render_opacity, viewpoint.exposure_a, viewpoint.exposure_b,
                             viewpoint.rgb, viewpoint.depth, _u8(viewpoint.mask), _u8(viewpoint.grad_mask), True,
                             False, 0.9)
+
+
+class LossGrads:
+    """Result of ``loss_grads``: upstream gradients for the rasteriser + views of the scalar results on the device."""
+    __slots__ = ("d_render", "d_depth", "scratch", "has_exposure")
+
+    def __init__(self, d_render, d_depth, scratch, has_exposure):
+        self.d_render, self.d_depth, self.scratch, self.has_exposure = d_render, d_depth, scratch, has_exposure
+
+    @property
+    def loss(self) -> torch.Tensor:                    # device scalar, valid once the two kernels have run
+        return self.scratch[_LOSS]
+
+    @property
+    def d_exposure_a(self):
+        return self.scratch[_DAB:_DAB + 1] if self.has_exposure else None
+
+    @property
+    def d_exposure_b(self):
+        return self.scratch[_DAB + 1:_DAB + 2] if self.has_exposure else None
+
+    def backward(self, render_image, render_depth, viewpoint=None, accumulate=False):
+        """Drive the rasteriser's backward with these gradients and hand the exposure gradients to the viewpoint."""
+        torch.autograd.backward([render_image, render_depth], [self.d_render, self.d_depth])
+        if viewpoint is not None and self.has_exposure:
+            for p, g in ((viewpoint.exposure_a, self.d_exposure_a), (viewpoint.exposure_b, self.d_exposure_b)):
+                p.grad = g if (p.grad is None or not accumulate) else p.grad + g
+
+
+@torch.no_grad()
+def loss_grads(render_image, render_depth, render_opacity, viewpoint, tracking: bool, init: bool = False,
+               lambda_depth: float = 0.9) -> LossGrads:
+    """``get_loss_tracking`` / ``get_loss_mapping`` (/root/reference/utils/slam_utils.py:58-146) as VALUE + GRADIENTS in two
+    launches, for loops that call the rasteriser's backward themselves: no autograd node for the scalar, hence no finalize
+    kernel, no ones-fill and no loss-summing adds (``loss.backward()`` on the fused autograd loss costs four launches per
+    render).  Same numbers as ``_FusedLoss`` forward + backward with grad_output = 1."""
+    lib = _lib.load()
+    render = _f32(render_image.detach(), "render_image")
+    depth = _f32(render_depth.detach(), "render_depth")
+    H, W = render.shape[-2:]
+    dev = render.device
+    opac = _f32(render_opacity.detach(), "render_opacity") if tracking else None
+    gt_rgb, gt_depth = _f32(viewpoint.rgb, "viewpoint.rgb"), _f32(viewpoint.depth, "viewpoint.depth")
+    a = None if init else _f32(viewpoint.exposure_a.detach(), "exposure_a")
+    b = None if init else _f32(viewpoint.exposure_b.detach(), "exposure_b")
+    mask = _u8(viewpoint.mask)
+    gm = _u8(viewpoint.grad_mask) if tracking else None
+    p = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+    with _device_guard(dev):
+        scratch = torch.empty(lib.mgs_loss_scratch_bytes() // 4, dtype=torch.float32, device=dev)
+        d_render, d_depth = torch.empty_like(render), torch.empty_like(depth)
+        _lib.check(lib.mgs_loss_grads(W, H, int(tracking), int(init), 0.9 if tracking else float(lambda_depth), p(render),
+                                      p(depth), p(opac), p(gt_rgb), p(gt_depth), p(mask), p(gm), p(a), p(b), p(scratch),
+                                      p(d_render), p(d_depth), _stream()), "mgs_loss_grads")
+    return LossGrads(d_render, d_depth, scratch, not init)

@@ -157,10 +157,11 @@ class TrackingGraph:
         color, _, depth, opacity, _ = GaussianRasterizer(rs)(
             means3D=xyz, means2D=self.zero2d, opacities=opa, colors_precomp=col, scales=sca3, rotations=rot,
             theta=self.svp.cam_rot_delta, rho=self.svp.cam_trans_delta)
-        pkg = {"render": color, "depth": depth, "opacity": opacity}
         self.opt.zero_grad()
-        loss = fused_losses.get_loss_tracking(pkg["render"], pkg["depth"], pkg["opacity"], self.svp)
-        loss.backward()      # (an explicit gradient= tensor costs ~140 ms on its first call and saves one 4 us fill)
+        # loss value + upstream gradients in two launches, then the rasteriser's backward directly: no autograd node for
+        # the scalar (its finalize kernel and the ones-fill of loss.backward() were two of the 25 launches of a replay)
+        lg = fused_losses.loss_grads(color, depth, opacity, self.svp, tracking=True)
+        lg.backward(color, depth, self.svp)
         self.opt.step_and_retract(sync=False)
 
     @torch.no_grad()
@@ -258,12 +259,25 @@ def run_slam(n_frames=12, intrinsics="fr3_office", tracking_itr_num=100, mapping
         kf_opt = torch.optim.Adam(pose_params) if pose_params else None
 
         def iteration():
-            loss = None
-            for vp in window:
-                pkg = _render(vp, intr, gmap, bg)
-                term = get_loss_mapping(pkg["render"], pkg["depth"], vp, init=init)
-                loss = term if loss is None else loss + term
-            loss.backward()
+            if fused_losses_on:          # value + gradients per keyframe, ONE backward through all the renders
+                outs, grads, lgs = [], [], []
+                for vp in window:
+                    pkg = _render(vp, intr, gmap, bg)
+                    lg = fused_losses.loss_grads(pkg["render"], pkg["depth"], None, vp, tracking=False, init=init)
+                    outs += [pkg["render"], pkg["depth"]]
+                    grads += [lg.d_render, lg.d_depth]
+                    lgs.append((vp, lg))
+                torch.autograd.backward(outs, grads)
+                for vp, lg in lgs:
+                    if lg.has_exposure:
+                        vp.exposure_a.grad, vp.exposure_b.grad = lg.d_exposure_a, lg.d_exposure_b
+            else:
+                loss = None
+                for vp in window:
+                    pkg = _render(vp, intr, gmap, bg)
+                    term = get_loss_mapping(pkg["render"], pkg["depth"], vp, init=init)
+                    loss = term if loss is None else loss + term
+                loss.backward()
             with torch.no_grad():
                 gmap.optimizer.step()
                 gmap.optimizer.zero_grad(set_to_none=True)

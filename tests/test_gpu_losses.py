@@ -81,3 +81,26 @@ def test_fused_losses_against_reference_golden(native_lib):
     assert abs(loss.item() - d["loss_track"][0]) < 2e-6
     assert np.allclose(gr.cpu().numpy(), d["grad_render_track"], atol=1e-8)
     assert np.allclose(gd.cpu().numpy(), d["grad_depth_track"], atol=1e-8)
+
+
+@pytest.mark.parametrize("tracking,init", [(True, False), (False, False), (False, True)])
+@pytest.mark.parametrize("H,W", [(480, 640), (237, 325)])
+def test_loss_grads_two_launch_path_equals_the_autograd_loss(native_lib, tracking, init, H, W):
+    """`loss_grads` (value + upstream gradients in two launches, no autograd node for the scalar -- what the captured
+    tracking / mapping iterations use) gives the numbers of the autograd loss forward + backward."""
+    from monogs_amd import fused_losses as F
+    vp, render, rdepth, op = _vp(H, W, 31, DEV)
+    if tracking:
+        loss = F.get_loss_tracking(render, rdepth, op, vp)
+    else:
+        loss = F.get_loss_mapping(render, rdepth, vp, init=init)
+    xs = [render, rdepth] + ([] if init else [vp.exposure_a, vp.exposure_b])
+    ref = _grads(loss, xs)
+    lg = F.loss_grads(render, rdepth, op if tracking else None, vp, tracking=tracking, init=init)
+    assert torch.allclose(lg.loss, loss.detach(), rtol=1e-6, atol=0)
+    assert torch.equal(lg.d_render, ref[0]) and torch.equal(lg.d_depth, ref[1])
+    if init:
+        assert lg.d_exposure_a is None
+    else:           # block-level float atomics: summation order varies
+        assert torch.allclose(lg.d_exposure_a, ref[2], rtol=1e-5, atol=1e-9)
+        assert torch.allclose(lg.d_exposure_b, ref[3], rtol=1e-5, atol=1e-9)

@@ -228,7 +228,8 @@ int mgs_pose_step(float* R, float* T, float* rot_delta, float* trans_delta, floa
                   const float* grad_rot, const float* grad_trans, const float* grad_a, const float* grad_b,
                   float* adam_m, float* adam_v, int32_t step, float lr_rot, float lr_trans, float lr_exposure,
                   float beta1, float beta2, float eps, float converged_threshold, int32_t* step_counter, float* out,
-                  int32_t flags, void* stream);
+                  int32_t flags, float* host_flag /* optional: pinned host word that also receives out[0] */,
+                  void* stream);
 
 /* ---- Keyframe back-projection ------------------------------------------------
  * The per-point part of GaussianModel.create_viewpoint_pcd (/root/reference/gaussian_splatting/scene/gaussian_model.py:121-319)

@@ -63,7 +63,8 @@ SIGNATURES = {
     "mgs_loss_grads": (C.c_int, [C.c_int32] * 4 + [C.c_float] + [C.c_void_p] * 9 + [C.c_void_p] * 4),
     "mgs_backproject": (C.c_int, [C.c_int32] * 3 + [C.c_void_p] * 6 + [C.c_float] * 4 + [C.c_void_p] * 6),
     "mgs_camera_setup": (C.c_int, [C.c_void_p] * 7),
-    "mgs_pose_step": (C.c_int, [C.c_void_p] * 12 + [C.c_int32] + [C.c_float] * 7 + [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "mgs_pose_step": (C.c_int, [C.c_void_p] * 12 + [C.c_int32] + [C.c_float] * 7
+                      + [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "mgs_adam_step": (C.c_int, [C.c_int32] + [C.c_void_p] * 6 + [C.c_double] * 3 + [C.c_int32, C.c_void_p, C.c_void_p]),
     "mgs_densify_stats": (C.c_int, [C.c_int32] + [C.c_void_p] * 6),
     "mgs_activate_forward": (C.c_int, [C.c_int32, C.c_int32] + [C.c_void_p] * 7),

@@ -38,8 +38,10 @@ class PoseAdam:
             p.grad = None
 
     @torch.no_grad()
-    def step_and_retract(self, converged_threshold=1e-4, sync=True):
-        """Returns the convergence flag (bool) when ``sync`` else the device tensor out[2]."""
+    def step_and_retract(self, converged_threshold=1e-4, sync=True, host_flag=None):
+        """Returns the convergence flag (bool) when ``sync`` else the device tensor out[2].  ``host_flag``: a PINNED
+        host float tensor whose first element the kernel also writes the flag to (device stores into mapped host memory:
+        a loop replayed from a hipGraph then needs no device-to-host copy per iteration)."""
         lib = _lib.load()
         vp = self.vp
         R = vp.R.contiguous() if not vp.R.is_contiguous() else vp.R
@@ -54,6 +56,7 @@ class PoseAdam:
                                          g(vp.exposure_a), g(vp.exposure_b), self.m.data_ptr(), self.v.data_ptr(),
                                          0, self.lrs[0], self.lrs[1], self.lrs[2], self.betas[0], self.betas[1],
                                          self.eps, float(converged_threshold), self.t_dev.data_ptr(),
-                                         self.out.data_ptr(), 1 if self.sticky else 0, _stream()),
+                                         self.out.data_ptr(), 1 if self.sticky else 0,
+                                         None if host_flag is None else host_flag.data_ptr(), _stream()),
                        "mgs_pose_step")
         return bool(self.out[0].item() > 0.5) if sync else self.out

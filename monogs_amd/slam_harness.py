@@ -134,18 +134,18 @@ class TrackingGraph:
         # two executable graphs of the same iteration, replayed alternately: launching a graph that is still running
         # waits for it, a second instance lets replay n+1 queue behind replay n (the ~30 us launch gap disappears)
         self.graphs = []
-        for _ in range(2):
+        for slot in range(2):
             self.opt.zero_grad()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                self._iteration()
+                self._iteration(host_flag=self.flags[slot])      # graph `slot` reports into its own pinned word
             self.graphs.append(g)
         self.graph = self.graphs[0]
         with torch.no_grad():          # undo the warm-up step
             self.svp.R.copy_(keep[0]); self.svp.T.copy_(keep[1])
             self.svp.exposure_a.data.copy_(keep[2]); self.svp.exposure_b.data.copy_(keep[3])
 
-    def _iteration(self):
+    def _iteration(self, host_flag=None):
         # render() without what tracking never reads: no screen-space gradient holder, no visibility filter
         xyz, rot, sca3, opa, col = self.map
         view, full, campos = cam.fused_camera_matrices(self.svp.R, self.svp.T, self.intr.projection_matrix)
@@ -162,7 +162,7 @@ class TrackingGraph:
         # the scalar (its finalize kernel and the ones-fill of loss.backward() were two of the 25 launches of a replay)
         lg = fused_losses.loss_grads(color, depth, opacity, self.svp, tracking=True)
         lg.backward(color, depth, self.svp)
-        self.opt.step_and_retract(sync=False)
+        self.opt.step_and_retract(sync=False, host_flag=host_flag)
 
     @torch.no_grad()
     def _load(self, vp: Viewpoint):
@@ -172,6 +172,8 @@ class TrackingGraph:
         s.exposure_a.data.copy_(vp.exposure_a.data); s.exposure_b.data.copy_(vp.exposure_b.data)
         s.cam_rot_delta.data.zero_(); s.cam_trans_delta.data.zero_()
         self.opt.reset()
+        for f in self.flags:          # (host words; nothing is in flight between two frames)
+            f.zero_()
 
     def track(self, vp: Viewpoint, max_iters: int, lookahead: int = 1) -> int:
         """lookahead = 0: read the convergence flag after every replay (one 4-byte read-back per iteration).
@@ -180,8 +182,7 @@ class TrackingGraph:
         self._load(vp)
         n_done = max_iters
         for n in range(max_iters):
-            self.graphs[n & 1].replay()
-            self.flags[n & 1].copy_(self.opt.out[:1], non_blocking=True)
+            self.graphs[n & 1].replay()          # its pose step stores the convergence flag into self.flags[n & 1] (pinned)
             self.events[n & 1].record()
             m = n - lookahead
             if m >= 0:

@@ -422,7 +422,7 @@ def main():
                                    f"(SURVEY.md 8d), one keyframe per GPU",
                        "gaussians": args.gaussians, "width": W, "height": H,
                        "instance_count": "device-side (capacity mode, overflow checked)" if sync_free else "host read-back per forward",
-                       "parallelism": f"keyframe-per-gpu x{world}" + (" + RCCL all-reduce of 12 floats/Gaussian" if world > 1 else "")
+                       "parallelism": f"keyframe-per-gpu x{world}" + (f" + RCCL all-reduce of 12 floats/Gaussian in {bucket.last_collectives} collective(s)" if bucket is not None else "")
                        + (" [REHEARSAL: ranks share a device, collectives over gloo]" if rehearsal else "")},
             "stages_ms": stages, "roofline": roof, "cpu_baseline": cpu, "slam": slam,
         }

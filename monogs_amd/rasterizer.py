@@ -275,14 +275,20 @@ class _RasterizeGaussians(torch.autograd.Function):
             g_color = _f32(grad_color, "grad_color") if grad_color is not None else torch.zeros(3, H, W, **f32)
             g_depth = _f32(grad_depth, "grad_depth") if grad_depth is not None else torch.zeros(1, H, W, **f32)
             out = lambda cond, *shape: torch.empty(*shape, **f32) if cond else None  # noqa: E731
-            d_means3D = out(need[0], P, 3)
             d_means2D = out(need[1], P, 3)
             d_sh = out(need[2] and has_sh, P, max(ctx.sh_coeffs, 1), 3)
-            d_col = out(need[3] and has_col, P, 3)
-            d_opac = out(need[4], P, 1)
-            d_scales = out(need[5] and has_sr, P, ctx.scale_dim)
-            d_rot = out(need[6] and has_sr, P, 4)
             d_cov = out(need[7] and has_cov, P, 6)
+            # The gradients of the replicated map parameters (xyz, colour, opacity, scale, rotation) are carved out of ONE
+            # allocation, in that order: a keyframe-sharded mapping window can then all-reduce them with a single
+            # collective over the flat storage, with no pack / unpack copies (window.GradBucket finds the adjacency).
+            widths = [3 if need[0] else 0, 3 if (need[3] and has_col) else 0, 1 if need[4] else 0,
+                      ctx.scale_dim if (need[5] and has_sr) else 0, 4 if (need[6] and has_sr) else 0]
+            flat = torch.empty(P * sum(widths), **f32) if sum(widths) else None
+            views, o = [], 0
+            for w in widths:
+                views.append(flat[o:o + P * w].view(P, w) if w else None)
+                o += P * w
+            d_means3D, d_col, d_opac, d_scales, d_rot = views
             want_tau = (need[8] and has_theta) or (need[9] and has_rho)
             d_tau = torch.empty(6, **f32) if want_tau else None
             scratch = torch.empty(lib.mgs_backward_bytes(P), dtype=torch.uint8, device=dev)

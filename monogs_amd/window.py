@@ -59,6 +59,22 @@ def all_gather_into_(out: torch.Tensor, inp: torch.Tensor, group=None):
 PER_TENSOR_BYTES = 32 << 20
 
 
+def flat_view(tensors: Sequence[torch.Tensor]) -> Optional[torch.Tensor]:
+    """One 1-D tensor that aliases ALL of ``tensors`` if they are contiguous, of one dtype, and laid out back to back in
+    one storage (as the rasteriser's backward allocates the map gradients); else None."""
+    ts = [t for t in tensors if t is not None]
+    if not ts or any((not t.is_contiguous()) or t.dtype != ts[0].dtype or t.device != ts[0].device for t in ts):
+        return None
+    base = ts[0].untyped_storage().data_ptr()
+    nxt = ts[0].data_ptr()
+    for t in ts:
+        if t.untyped_storage().data_ptr() != base or t.data_ptr() != nxt:
+            return None
+        nxt += t.numel() * t.element_size()
+    total = sum(t.numel() for t in ts)
+    return ts[0].as_strided((total,), (1,), ts[0].storage_offset())
+
+
 class GradBucket:
     """One flat [P, C] float32 buffer holding every Gaussian gradient column, reduced in one call
     (or, for large maps, the gradient tensors themselves reduced in place)."""
@@ -72,6 +88,7 @@ class GradBucket:
         self.per_tensor = (total_bytes > PER_TENSOR_BYTES) if per_tensor is None else per_tensor
         cols = extra_cols if self.per_tensor else sum(self.widths) + extra_cols
         self.buf = torch.zeros(P, cols, dtype=torch.float32, device=self.params[0].device)
+        self.last_collectives = 1            # collectives issued by the last all_reduce()
 
     def pack(self, extra: Optional[torch.Tensor] = None):
         c = 0
@@ -115,7 +132,10 @@ class GradBucket:
         if not (dist.is_available() and dist.is_initialized()):
             return None
         if self.per_tensor:
-            tensors = [p.grad for p in self.params] + ([self.buf] if self.extra_cols else [])
+            grads = [p.grad for p in self.params]
+            flat = flat_view(grads)             # back-to-back gradients (the rasteriser's own allocation): ONE collective
+            tensors = ([flat] if flat is not None else grads) + ([self.buf] if self.extra_cols else [])
+            self.last_collectives = len(tensors)
             works = [all_reduce_(t, group=group, async_op=True) for t in tensors]
             works = [w for w in works if w is not None]
             if async_op:

@@ -206,3 +206,21 @@ def test_two_rank_exchanges_with_oracle_renders(tmp_path):
             assert torch.equal(got[2], ref.exposure_a.data) and torch.equal(got[3], ref.exposure_b.data)
     assert torch.equal(r0["draws"][0], r1["draws"][0]) and not torch.equal(r0["draws"][0], r0["draws"][1])
     assert r0["sync"] and r1["sync"] and not r0["sync_bad"] and not r1["sync_bad"]
+
+
+def test_flat_view_finds_back_to_back_gradients():
+    from monogs_amd.window import flat_view
+    P = 37
+    flat = torch.arange(P * 12, dtype=torch.float32)
+    views, o = [], 0
+    for w in (3, 3, 1, 1, 4):
+        views.append(flat[o:o + P * w].view(P, w))
+        o += P * w
+    fv = flat_view(views)
+    assert fv is not None and fv.shape == (P * 12,) and fv.data_ptr() == flat.data_ptr()
+    fv.mul_(2)                                              # aliases the gradients
+    assert torch.equal(views[4], (flat[P * 8:]).view(P, 4)) and float(views[0][0, 1]) == 2.0
+    assert flat_view([views[0], views[2]]) is None         # a gap
+    assert flat_view([views[0], torch.zeros(P, 3)]) is None  # another storage
+    assert flat_view([views[0].t()]) is None               # not contiguous
+    assert flat_view([]) is None

@@ -78,6 +78,15 @@ class WindowMapper:
             po = self._pose_opt[id(vp)] = PoseAdam(vp, *self.lrs)
         return po
 
+    def new_keyframe_optimizers(self, viewpoints: Sequence = ()):
+        """What the mapper does whenever a keyframe joins the window: ``self.keyframe_optimizers = torch.optim.Adam(...)``
+        over the window's pose / exposure parameters (/root/reference/utils/slam_mapper.py:669-719) -- a FRESH optimiser,
+        i.e. zero moments and step counts for every keyframe of the window.  Call it before the ``optimize_map`` calls
+        of a new keyframe; between them (``prune=False`` then ``prune=True``) the state carries over, as there."""
+        self._pose_opt = {k: v for k, v in self._pose_opt.items() if any(k == id(vp) for vp in viewpoints)}
+        for po in self._pose_opt.values():
+            po.reset()
+
     def owned(self, n_keyframes: int) -> List[int]:
         return W.shard_keyframes(n_keyframes, self.rank, self.world)
 

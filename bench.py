@@ -398,7 +398,7 @@ def main():
             from monogs_amd.slam_harness import run_slam
             r = run_slam(n_frames=6, intrinsics="fr3_office", tracking_itr_num=100, mapping_itr_num=150, window_size=8,
                          kf_interval=5, init_itr_num=150, graph_tracking=True, graph_mapping=True)
-            slam = {k: (round(v, 3) if isinstance(v, float) else v) for k, v in r.items()
+            slam = {k: (round(v, 6 if k == "ate_rmse_m" else 3) if isinstance(v, float) else v) for k, v in r.items()
                     if k in ("tracking_fps", "tracking_iters_per_s", "mapping_iters_per_s", "mapping_kf_per_s",
                              "tracking_steady_iters_per_s", "mapping_steady_iters_per_s", "kf_extend_ms",
                              "ate_rmse_m", "gaussians", "width", "height", "frames", "config", "graph_tracking", "graph_mapping")}

@@ -95,11 +95,14 @@ def _run_densify(rank, world, port, out):
     for _ in range(5):
         mapper.optimize_map(frames, iters=1)
         sizes.append(len(gmap))
+    had_state = any(int(po.t_dev.item()) > 0 for po in mapper._pose_opt.values())
+    mapper.new_keyframe_optimizers(frames)                                   # a keyframe joins: fresh pose-optimiser state
+    fresh = all(int(po.t_dev.item()) == 0 and float(po.m.abs().sum()) == 0 for po in mapper._pose_opt.values())
     mapper.optimize_map(frames, prune=True, iters=1)                         # full window: covisibility prune
     sizes.append(len(gmap))
     ok = replicas_in_sync(gmap.params() + [gmap.xyz_gradient_accum, gmap.denom, gmap.max_radii_2d,
                                            gmap.kf_idx.float(), gmap.nr_obs.float()] + gmap.optimizer.exp_avg)
-    torch.save(dict(n0=n0, sizes=sizes, in_sync=ok, steps=gmap.optimizer.t_dev.cpu(),
+    torch.save(dict(n0=n0, sizes=sizes, in_sync=ok, steps=gmap.optimizer.t_dev.cpu(), pose_reset=had_state and fresh,
                     vis_len=[int(v.shape[0]) for v in mapper.occ_aware_visibility.values()],
                     finite=all(bool(torch.isfinite(p).all()) for p in gmap.params())), f"{out}.d{world}.{rank}")
     if world > 1:
@@ -118,6 +121,7 @@ def test_two_rank_map_surgery_stays_in_sync(native_lib, tmp_path):
     assert r0["sizes"][1] != r0["n0"] and r0["sizes"][3] != r0["sizes"][2], r0["sizes"]      # both densify steps changed the map
     assert all(n == r0["sizes"][-1] for n in r0["vis_len"]) and len(r0["vis_len"]) == N_KF    # visibility re-indexed by the prune
     assert torch.equal(r0["steps"], r1["steps"])
+    assert r0["pose_reset"] and r1["pose_reset"]
 
 
 def _rel(a, b):

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define MGS_ABI_VERSION 4
+#define MGS_ABI_VERSION 5
 #define MGS_TILE 16 /* tile edge in pixels; ranges are per 16x16 tile */
 
 /* GaussianRasterizationSettings, minus `prefiltered` / `debug` which are call flags
@@ -85,12 +85,19 @@ size_t mgs_geometry_bytes(int32_t P);
 size_t mgs_image_bytes(int32_t width, int32_t height);
 size_t mgs_binning_bytes(uint64_t num_rendered, int32_t width, int32_t height);
 size_t mgs_backward_bytes(int32_t P);
+/* The six floats inside a backward scratch that a PREPARED backward (below) accumulates dL/dtau into. */
+float* mgs_backward_tau(void* backward_scratch, int32_t P);
 
 /* Forward, stage 1: per-Gaussian projection (cull, covariance, radius, tile rectangle, colour), the depth
  * order of the Gaussians and the prefix sum of tiles touched in that order.  Writes radii[P] and the geometry scratch, then copies the total number
  * of (Gaussian, tile) instances to *num_rendered [host] -- this synchronises `stream`, exactly as the
  * upstream forward does, because the caller must size the binning scratch from it.
- * Exactly one of (shs, colors_precomp) and exactly one of ((scales, rotations), cov3D_precomp) is non-NULL. */
+ * Exactly one of (shs, colors_precomp) and exactly one of ((scales, rotations), cov3D_precomp) is non-NULL.
+ * `prepare_backward`: NULL, or the scratch (mgs_backward_bytes(P)) of the ONE backward that will follow this forward.
+ * The per-Gaussian kernel then also clears what that backward accumulates into -- the 64-byte gradient line of every
+ * VISIBLE Gaussian (the others are never touched), the pose-gradient slots and the six floats at
+ * mgs_backward_tau(scratch, P) -- and mgs_backward may be called with scratch_prepared = 1: no clearing launch and no
+ * 64 B x P fill per backward. */
 int mgs_forward_preprocess(const mgs_camera* cam, int32_t P,
                            const float* means3D,        /* [P,3] */
                            const float* shs,            /* [P,M,3] or NULL */
@@ -100,6 +107,7 @@ int mgs_forward_preprocess(const mgs_camera* cam, int32_t P,
                            const float* rotations,      /* [P,4] or NULL */
                            const float* cov3D_precomp,  /* [P,6] or NULL */
                            void* geometry, int32_t* radii /* [P] */,
+                           void* prepare_backward /* backward scratch to clear, or NULL */,
                            uint64_t* num_rendered /* [host]; NULL = capacity mode, no sync */,
                            mgs_timing* timing /* [host] or NULL */, void* stream);
 
@@ -143,7 +151,9 @@ int mgs_forward_render_capacity(const mgs_camera* cam, int32_t P, uint64_t capac
 
 /* Backward.  Consumes dL/dcolor[3,H,W] and dL/ddepth[1,H,W] (dL/dopacity is ignored, as upstream) and
  * the scratch of the matching forward.  Any output pointer may be NULL (that gradient is then not
- * stored); dL_dtau is [6] = (rho, theta), already summed over Gaussians. */
+ * stored); dL_dtau is [6] = (rho, theta), already summed over Gaussians.
+ * scratch_prepared = 1: `backward_scratch` was handed to the matching mgs_forward_preprocess as prepare_backward and has
+ * not been used by a backward since; dL_dtau must then be NULL or mgs_backward_tau(backward_scratch, P). */
 int mgs_backward(const mgs_camera* cam, int32_t P, uint64_t num_rendered,
                  const float* means3D, const float* shs, const float* colors_precomp,
                  const float* opacities, const float* scales, const float* rotations,
@@ -159,7 +169,7 @@ int mgs_backward(const mgs_camera* cam, int32_t P, uint64_t num_rendered,
                  float* dL_dscales,   /* [P,3] */
                  float* dL_drotations,/* [P,4] */
                  float* dL_dtau,      /* [6]   */
-                 void* backward_scratch, mgs_timing* timing, void* stream);
+                 void* backward_scratch, int32_t scratch_prepared, mgs_timing* timing, void* stream);
 
 /* Diagnostic (not on the hot path): counts what the blend backward of the matching forward does, into
  * stats_dev[8] (device uint64): [0] 64-instance steps walked, [1] instances that pass the per-quadrant cull and are
@@ -222,13 +232,17 @@ int mgs_loss_grads(int32_t width, int32_t height, int32_t tracking, int32_t init
  * can be captured in a hipGraph and replayed);
  * out[2] = {converged (|tau| < converged_threshold ? 1 : 0), |tau|}.  exposure pointers / any gradient may be NULL.
  * flags: MGS_POSE_STICKY makes the call a no-op once out[0] reports convergence (the tracker's early exit,
- * /root/reference/utils/slam_tracker.py:172-176, for loops replayed from a hipGraph); zero out[] to start over. */
+ * /root/reference/utils/slam_tracker.py:172-176, for loops replayed from a hipGraph); zero out[] to start over.
+ * Camera refresh (optional, all four or none): with viewmatrix / projmatrix / campos non-NULL the kernel also recomputes
+ * the viewpoint's camera tensors from the NEW R, T and projmatrix_raw -- bit-identical to mgs_camera_setup -- so the next
+ * render of the loop needs no camera launch of its own. */
 #define MGS_POSE_STICKY 1
 int mgs_pose_step(float* R, float* T, float* rot_delta, float* trans_delta, float* exposure_a, float* exposure_b,
                   const float* grad_rot, const float* grad_trans, const float* grad_a, const float* grad_b,
                   float* adam_m, float* adam_v, int32_t step, float lr_rot, float lr_trans, float lr_exposure,
                   float beta1, float beta2, float eps, float converged_threshold, int32_t* step_counter, float* out,
                   int32_t flags, float* host_flag /* optional: pinned host word that also receives out[0] */,
+                  const float* projmatrix_raw, float* viewmatrix, float* projmatrix, float* campos /* optional refresh */,
                   void* stream);
 
 /* ---- Keyframe back-projection ------------------------------------------------

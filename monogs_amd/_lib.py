@@ -11,7 +11,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MGS_LIB_PATH") or os.path.join(_HERE, "lib", "libmonogs_raster.so")   # (override: kernel experiments)
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 c_float_p = C.c_void_p   # device pointers travel as integers (tensor.data_ptr())
 
@@ -44,7 +44,7 @@ SIGNATURES = {
     "mgs_binning_bytes": (C.c_size_t, [C.c_uint64, C.c_int32, C.c_int32]),
     "mgs_backward_bytes": (C.c_size_t, [C.c_int32]),
     "mgs_forward_preprocess": (C.c_int, [C.POINTER(MgsCamera), C.c_int32] + [C.c_void_p] * 7
-                               + [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(MgsTiming), C.c_void_p]),
+                               + [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(MgsTiming), C.c_void_p]),
     "mgs_forward_render": (C.c_int, [C.POINTER(MgsCamera), C.c_int32, C.c_uint64] + [C.c_void_p] * 8
                            + [C.POINTER(MgsTiming), C.c_void_p]),
     "mgs_debug_set_radix_spin_limit": (C.c_int, [C.c_uint32]),
@@ -53,7 +53,8 @@ SIGNATURES = {
                                     + [C.POINTER(MgsTiming), C.c_void_p]),
     "mgs_backward": (C.c_int, [C.POINTER(MgsCamera), C.c_int32, C.c_uint64] + [C.c_void_p] * 7
                      + [C.c_void_p] * 4 + [C.c_void_p] * 2 + [C.c_void_p] * 9
-                     + [C.c_void_p, C.POINTER(MgsTiming), C.c_void_p]),
+                     + [C.c_void_p, C.c_int32, C.POINTER(MgsTiming), C.c_void_p]),
+    "mgs_backward_tau": (C.c_void_p, [C.c_void_p, C.c_int32]),
     "mgs_debug_blend_stats": (C.c_int, [C.POINTER(MgsCamera), C.c_int32, C.c_uint64] + [C.c_void_p] * 5),
     "mgs_mark_visible": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mgs_loss_scratch_bytes": (C.c_size_t, []),
@@ -64,7 +65,7 @@ SIGNATURES = {
     "mgs_backproject": (C.c_int, [C.c_int32] * 3 + [C.c_void_p] * 6 + [C.c_float] * 4 + [C.c_void_p] * 6),
     "mgs_camera_setup": (C.c_int, [C.c_void_p] * 7),
     "mgs_pose_step": (C.c_int, [C.c_void_p] * 12 + [C.c_int32] + [C.c_float] * 7
-                      + [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+                      + [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p] + [C.c_void_p] * 4 + [C.c_void_p]),
     "mgs_adam_step": (C.c_int, [C.c_int32] + [C.c_void_p] * 6 + [C.c_double] * 3 + [C.c_int32, C.c_void_p, C.c_void_p]),
     "mgs_densify_stats": (C.c_int, [C.c_int32] + [C.c_void_p] * 6),
     "mgs_activate_forward": (C.c_int, [C.c_int32, C.c_int32] + [C.c_void_p] * 7),

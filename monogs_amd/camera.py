@@ -34,24 +34,48 @@ def world2view(R: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
     return M
 
 
-def fused_camera_matrices(R: torch.Tensor, t: torch.Tensor, projmatrix_raw: torch.Tensor):
+def fused_camera_matrices(R: torch.Tensor, t: torch.Tensor, projmatrix_raw: torch.Tensor, out=None):
     """(viewmatrix, projmatrix, campos) -- the three transposed camera tensors of GaussianRasterizationSettings --
     from device tensors R[3,3], t[3] (world->camera) and the transposed projection, in one launch
     (``mgs_camera_setup``).  Same values as ``world2view(R, t).T``, ``viewmatrix @ projmatrix_raw`` and
-    ``viewmatrix.inverse()[3, :3]``; no autograd (the rasteriser gives the camera tensors no gradient)."""
+    ``viewmatrix.inverse()[3, :3]``; no autograd (the rasteriser gives the camera tensors no gradient).
+    ``out``: three existing tensors to write into (a loop whose pose step keeps them current -- ``PoseAdam.step_and_retract(camera=...)`` --
+    computes them once per frame, not once per render)."""
     from . import _lib
     from .rasterizer import _stream, _device_guard
     lib = _lib.load()
     f = lambda x: x.detach().to(torch.float32).contiguous()  # noqa: E731
     R, t, Pm = f(R), f(t), f(projmatrix_raw)
     dev = R.device
-    view = torch.empty(4, 4, dtype=torch.float32, device=dev)
-    full = torch.empty(4, 4, dtype=torch.float32, device=dev)
-    campos = torch.empty(3, dtype=torch.float32, device=dev)
+    if out is not None:
+        view, full, campos = out
+    else:
+        view = torch.empty(4, 4, dtype=torch.float32, device=dev)
+        full = torch.empty(4, 4, dtype=torch.float32, device=dev)
+        campos = torch.empty(3, dtype=torch.float32, device=dev)
     with _device_guard(dev):
         _lib.check(lib.mgs_camera_setup(R.data_ptr(), t.data_ptr(), Pm.data_ptr(), view.data_ptr(), full.data_ptr(),
                                         campos.data_ptr(), _stream()), "mgs_camera_setup")
     return view, full, campos
+
+
+def cached_camera_tensors(viewpoint, R: torch.Tensor, t: torch.Tensor, projmatrix_raw: torch.Tensor):
+    """``fused_camera_matrices`` remembered on the viewpoint object: recomputed only when ``R``, ``t`` or the projection
+    are different tensor OBJECTS from the ones the cache was made from (``update_RT`` assigns new tensors, as the
+    reference's ``Camera.update_RT`` does, utils/camera_utils.py:165-167).  ``PoseAdam.step_and_retract`` updates
+    R, t in place and rewrites the cached tensors in the same launch, so a mapping / tracking loop launches no camera
+    kernel per render.  Falls back to a plain call for objects that take no new attributes."""
+    c = getattr(viewpoint, "_mgs_cam", None)
+    if c is not None and c[0] is R and c[1] is t and c[2] is projmatrix_raw:
+        return c[3]
+    out = fused_camera_matrices(R, t, projmatrix_raw)
+    ok = (R.dtype == torch.float32 and t.dtype == torch.float32 and projmatrix_raw.dtype == torch.float32
+          and R.is_contiguous() and t.is_contiguous() and projmatrix_raw.is_contiguous())
+    try:
+        viewpoint._mgs_cam = (R, t, projmatrix_raw, out) if ok else None
+    except AttributeError:
+        pass
+    return out
 
 
 def projection_matrix(fx, fy, cx, cy, W, H, znear=ZNEAR, zfar=ZFAR, device="cpu") -> torch.Tensor:

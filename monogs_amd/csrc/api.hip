@@ -37,8 +37,10 @@ GeometryState GeometryState::carve(void* base, int P) {
     g.clamped = (uint8_t*)take(p, (size_t)P * 4);
     g.rect = (uint2*)take(p, (size_t)P * sizeof(uint2));
     g.rect_sorted = (uint2*)take(p, (size_t)P * sizeof(uint2));
+    g.scan_status = (uint64_t*)take(p, SCAN_SMALL_MAX_BLOCKS * sizeof(uint64_t));
+    g.tile_hist = (uint32_t*)take(p, 4 * 256 * sizeof(uint32_t));
     g.sort_temp_bytes = mgs::sort_temp_bytes((uint64_t)P, 32);
-    g.sort_temp = take(p, g.sort_temp_bytes);
+    g.sort_temp = take(p, g.sort_temp_bytes);           // 256-aligned, directly behind tile_hist
     g.end = p;
     return g;
 }
@@ -130,13 +132,14 @@ size_t mgs_geometry_bytes(int32_t P) { return GeometryState::bytes(P < 0 ? 0 : P
 size_t mgs_image_bytes(int32_t W, int32_t H) { return ImageState::bytes(W, H); }
 size_t mgs_binning_bytes(uint64_t R, int32_t W, int32_t H) { return BinningState::bytes(R, W, H); }
 size_t mgs_backward_bytes(int32_t P) {
-    return (size_t)(P < 0 ? 0 : P) * GRAD_FLOATS * sizeof(float) + (size_t)TAU_SLOTS * 16 * sizeof(float) + 256;
+    return (size_t)(P < 0 ? 0 : P) * GRAD_FLOATS * sizeof(float) + (size_t)(TAU_SLOTS + 1) * 16 * sizeof(float) + 256;
 }
+float* mgs_backward_tau(void* backward_scratch, int32_t P) { return backward_tau_out(backward_scratch, P < 0 ? 0 : P); }
 
 int mgs_forward_preprocess(const mgs_camera* cam, int32_t P, const float* means3D, const float* shs,
                            const float* colors_precomp, const float* opacities, const float* scales,
                            const float* rotations, const float* cov3D_precomp, void* geometry, int32_t* radii,
-                           uint64_t* num_rendered, mgs_timing* timing, void* stream) {
+                           void* prepare_backward, uint64_t* num_rendered, mgs_timing* timing, void* stream) {
     if (check_cam(cam)) return 1;
     if (P < 0) { set_error("P must be >= 0"); return 1; }
     if (num_rendered) *num_rendered = 0;        // NULL = capacity mode: no read-back, no stream sync
@@ -160,7 +163,8 @@ int mgs_forward_preprocess(const mgs_camera* cam, int32_t P, const float* means3
     StageTimer tm(s, timing != nullptr);
     tm.mark();
     if (int rc = launch_preprocess_forward(*cam, P, means3D, shs, colors_precomp, opacities, scales, rotations,
-                                           cov3D_precomp, g, radii, s)) return rc;
+                                           cov3D_precomp, g, radii,
+                                           prepare_backward ? backward_grad_acc(prepare_backward) : nullptr, s)) return rc;
     tm.mark();
     if (int rc = launch_depth_sort(g, P, s)) return rc;
     tm.mark();
@@ -207,7 +211,7 @@ static int forward_render_impl(const mgs_camera* cam, int32_t P, uint64_t R, boo
     if (int rc = launch_duplicate(*cam, P, g, b, capacity ? R : (R > 0 ? 0xFFFFFFFFull : 0ull), n_touched, img, R,
                                   tile_bits(W, H), cap ? b.count : nullptr, overflow, s)) return rc;
     tm.mark();
-    if (int rc = launch_sort(b, R, tile_bits(W, H), s, n_dev)) return rc;
+    if (int rc = launch_sort(g, b, R, tile_bits(W, H), s, n_dev)) return rc;
     tm.mark();
     if (int rc = launch_ranges(b, R, img, tiles_x(W) * tiles_y(H), tile_bits(W, H), s, n_dev, overflow)) return rc;
     tm.mark();
@@ -244,7 +248,7 @@ int mgs_backward(const mgs_camera* cam, int32_t P, uint64_t R, const float* mean
                  const void* image, const float* dL_dcolor, const float* dL_ddepth, float* dL_dmeans2D,
                  float* dL_dcolors, float* dL_dopacity, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh,
                  float* dL_dscales, float* dL_drotations, float* dL_dtau, void* backward_scratch,
-                 mgs_timing* timing, void* stream) {
+                 int32_t scratch_prepared, mgs_timing* timing, void* stream) {
     if (check_cam(cam)) return 1;
     hipStream_t s = (hipStream_t)stream;
     if (P == 0) {
@@ -260,12 +264,20 @@ int mgs_backward(const mgs_camera* cam, int32_t P, uint64_t R, const float* mean
     GeometryState g = GeometryState::carve(const_cast<void*>(geometry), P);
     ImageState img = ImageState::carve(const_cast<void*>(image), W, H);
     BinningState b = BinningState::carve(const_cast<void*>(binning), R, W, H);
-    float* grad_acc = (float*)align_up((size_t)backward_scratch, 256);
+    float* grad_acc = backward_grad_acc(backward_scratch);
     StageTimer tm(s, timing != nullptr);
     // (the pose-gradient slots sit right behind the accumulator: one clear covers both)
-    float* tau_part = (dL_dtau && (P + 255) / 256 > TAU_DIRECT_MAX_BLOCKS) ? grad_acc + (size_t)P * GRAD_FLOATS : nullptr;
-    MGS_HIP(zero_fill2(grad_acc, (size_t)P * GRAD_FLOATS * sizeof(float) + (tau_part ? (size_t)TAU_SLOTS * 16 * sizeof(float) : 0),
-                       dL_dtau, 6 * sizeof(float), s));
+    float* tau_part = (dL_dtau && (P + 255) / 256 > TAU_DIRECT_MAX_BLOCKS) ? backward_tau_part(backward_scratch, P) : nullptr;
+    if (scratch_prepared) {
+        // the matching forward cleared the lines of the visible Gaussians, the slots and the six floats of dL/dtau
+        if (dL_dtau && dL_dtau != backward_tau_out(backward_scratch, P)) {
+            set_error("scratch_prepared: dL_dtau must be mgs_backward_tau(backward_scratch, P)");
+            return 1;
+        }
+    } else {
+        MGS_HIP(zero_fill2(grad_acc, (size_t)P * GRAD_FLOATS * sizeof(float) + (tau_part ? (size_t)TAU_SLOTS * 16 * sizeof(float) : 0),
+                           dL_dtau, 6 * sizeof(float), s));
+    }
     tm.mark();
     if (R > 0) {
         // colours / opacities take no gradient and do not feed the geometry (no SH): the lighter blend backward

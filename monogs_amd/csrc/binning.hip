@@ -78,6 +78,59 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_blocks_kernel(uint32_t* blo
     if (threadIdx.x == 0) block_sums[nblocks] = carry;      // grand total = number of instances R (read back by the exact path)
 }
 
+// ONE launch for P <= SCAN_SMALL_MAX_BLOCKS * SCAN_ITEMS (every SLAM-sized map): each workgroup publishes its total as a
+// self-describing 8-byte word {1 << 63 | total} (one relaxed agent-scope store, polled with relaxed agent-scope loads:
+// the radix sort's protocol), lane j of its first wave waits for workgroup j < blockIdx.x, the wave adds them up.  All
+// <= 64 workgroups are co-resident (one per CU), so nobody waits for a workgroup that has not started; the spin is
+// bounded anyway and raises the depth sort's error word (the consumers of the scan are the consumers of that sort).
+// out[] then holds GLOBAL inclusive sums; the grand total still goes to block_sums[nblocks].
+constexpr uint32_t SCAN_SPIN_LIMIT = 1u << 22;
+__global__ void __launch_bounds__(SCAN_THREADS) scan_small_kernel(const uint2* __restrict__ rects, uint32_t* out,
+                                                                  uint32_t* block_sums, uint64_t* status, int n, int nb,
+                                                                  uint32_t* err) {
+    __shared__ uint32_t smem[8];
+    __shared__ uint32_t s_prefix;
+    const int base = blockIdx.x * SCAN_ITEMS + threadIdx.x * SCAN_PER_THREAD;
+    uint32_t v[SCAN_PER_THREAD];
+    uint32_t sum = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_PER_THREAD; ++i) {
+        const uint32_t wh = (base + i < n) ? rects[base + i].y : 0u;
+        v[i] = (wh & 0xFFFFu) * (wh >> 16);
+        sum += v[i];
+    }
+    uint32_t total;
+    uint32_t run = block_excl_scan(sum, total, smem);
+    if (threadIdx.x == 0)
+        __hip_atomic_store(status + blockIdx.x, (1ull << 63) | (uint64_t)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x < WAVE) {
+        uint32_t before = 0;
+        if ((int)threadIdx.x < (int)blockIdx.x) {
+            uint64_t w = 0;
+            uint32_t spins = 0;
+            while (true) {
+                w = __hip_atomic_load(status + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (w >> 63) break;
+                if (++spins > SCAN_SPIN_LIMIT) { atomicExch(err, 1u); break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            before = (uint32_t)w;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o, 64);
+        if (threadIdx.x == 0) s_prefix = before;
+    }
+    __syncthreads();
+    run += s_prefix;
+#pragma unroll
+    for (int i = 0; i < SCAN_PER_THREAD; ++i) {
+        run += v[i];
+        if (base + i < n) out[base + i] = run;
+    }
+    if (threadIdx.x == 0 && (int)blockIdx.x == nb - 1) block_sums[nb] = s_prefix + total;
+}
+bool scan_is_small(int P) { return scan_nblocks(P) <= SCAN_SMALL_MAX_BLOCKS; }
+
 // (There is no third "add the block offset" pass: the only consumer of the offsets, duplicate_kernel, adds
 //  block_sums[i / SCAN_ITEMS] itself -- one launch and a 16-byte-per-Gaussian read-modify-write less.)
 
@@ -86,6 +139,12 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_blocks_kernel(uint32_t* blo
 int launch_scan(const GeometryState& g, int P, hipStream_t s) {
     if (P == 0) return 0;
     const int nb = scan_nblocks(P);
+    if (scan_is_small(P)) {
+        hipLaunchKernelGGL(scan_small_kernel, dim3(nb), dim3(SCAN_THREADS), 0, s, g.rect_sorted, g.point_offsets, g.scan_blocks,
+                           g.scan_status, P, nb, const_cast<uint32_t*>(radix_error_flag(g.sort_temp, (uint64_t)P, 32)));
+        MGS_HIP(hipGetLastError());
+        return 0;
+    }
     hipLaunchKernelGGL(scan_local_kernel, dim3(nb), dim3(SCAN_THREADS), 0, s, g.rect_sorted, g.point_offsets,
                        g.scan_blocks, P);
     hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(SCAN_THREADS), 0, s, g.scan_blocks, nb);
@@ -106,7 +165,8 @@ __global__ void __launch_bounds__(256) duplicate_kernel(int P, const uint2* __re
                                                         int32_t* __restrict__ n_touched, uint2* __restrict__ ranges,
                                                         int ntiles, uint32_t* __restrict__ zero_ptr, size_t zero_words,
                                                         uint32_t* __restrict__ count, uint32_t* __restrict__ overflow,
-                                                        const uint32_t* __restrict__ depth_err) {
+                                                        const uint32_t* __restrict__ depth_err, int offsets_global,
+                                                        uint32_t* __restrict__ hist /* [4][256] or NULL */, int hist_passes) {
     const int i = blockIdx.x * 256 + threadIdx.x;          // (launched with 256 threads; blockDim would be a packet fetch)
     const int lane = threadIdx.x & 63;
     {   // scratch of the tile sort that follows (was its own launch); the launch has max(P, ntiles) threads, rounded up
@@ -137,7 +197,7 @@ __global__ void __launch_bounds__(256) duplicate_kernel(int P, const uint2* __re
         x0 = (int)(r.x & 0xFFFFu); y0 = (int)(r.x >> 16); x1 = x0 + w;
     }
     if (depth_bad) nt = 0;                               // (wave-uniform, grid-uniform)
-    if (nt) off = i == 0 ? 0u : offsets[i - 1] + block_sums[(i - 1) / SCAN_ITEMS];
+    if (nt) off = i == 0 ? 0u : offsets[i - 1] + (offsets_global ? 0u : block_sums[(i - 1) / SCAN_ITEMS]);
     // Load-balanced emission.  The 64 Gaussians of the wave own the consecutive output slots [S, E); the wave walks
     // that range 64 slots at a time (aligned, so every store is one coalesced 256-byte line) and each lane finds the
     // owner of its slot: owners mark their first slot in LDS, an inclusive max-scan spreads the mark to the right.
@@ -145,13 +205,20 @@ __global__ void __launch_bounds__(256) duplicate_kernel(int P, const uint2* __re
     __shared__ uint32_t s_own[4][WAVE];
     __shared__ uint32_t s_idx[4][WAVE], s_off[4][WAVE];
     __shared__ int s_x0[4][WAVE], s_y0[4][WAVE], s_w[4][WAVE];
+    // Digit counts of the emitted tile ids (every pass of the tile sort), collected in LDS while the keys are written and
+    // added to the global table once per workgroup: the one-sweep sort then needs no histogram launch of its own.
+    __shared__ uint32_t s_hist[2][256];                                     // tile ids have <= 16 bits: two digits
+    if (hist) {
+        s_hist[0][threadIdx.x] = 0u; s_hist[1][threadIdx.x] = 0u;
+        __syncthreads();
+    }
     const int wv = threadIdx.x >> 6;
     s_idx[wv][lane] = idx; s_off[wv][lane] = off; s_x0[wv][lane] = x0; s_y0[wv][lane] = y0; s_w[wv][lane] = max(x1 - x0, 1);
     const unsigned long long live = __builtin_amdgcn_ballot_w64(nt != 0);
-    if (live == 0ull) return;                                               // wave-uniform
-    const int first = __builtin_ctzll(live), lastl = 63 - __builtin_clzll(live);
-    const uint32_t S = (uint32_t)__builtin_amdgcn_readlane((int)off, first);
-    const uint32_t E = (uint32_t)__builtin_amdgcn_readlane((int)(off + nt), lastl);
+    if (live == 0ull && !hist) return;                                      // wave-uniform
+    const int first = live ? __builtin_ctzll(live) : 0, lastl = live ? 63 - __builtin_clzll(live) : 0;
+    const uint32_t S = live ? (uint32_t)__builtin_amdgcn_readlane((int)off, first) : 0u;
+    const uint32_t E = live ? (uint32_t)__builtin_amdgcn_readlane((int)(off + nt), lastl) : 0u;
     uint32_t carry = 0;                                                     // owner (lane + 1) of the slot before the chunk
     for (uint32_t cb = S & ~63u; cb < E; cb += WAVE) {
         __builtin_amdgcn_wave_barrier();
@@ -172,9 +239,27 @@ __global__ void __launch_bounds__(256) duplicate_kernel(int P, const uint2* __re
             const uint32_t t = o - s_off[wv][L];
             const uint32_t w = (uint32_t)s_w[wv][L];
             const uint32_t yy = t / w, xx = t - yy * w;
-            keys[o] = (uint32_t)((s_y0[wv][L] + (int)yy) * gx + s_x0[wv][L] + (int)xx);
+            const uint32_t key = (uint32_t)((s_y0[wv][L] + (int)yy) * gx + s_x0[wv][L] + (int)xx);
+            keys[o] = key;
             vals[o] = s_idx[wv][L];
+            if (hist) {
+                atomicAdd(&s_hist[0][key & 0xFFu], 1u);
+                if (hist_passes > 1) {
+                    // the high digit takes a handful of values: the lanes that share the first active lane's digit add once
+                    const uint32_t d1 = (key >> 8) & 0xFFu;
+                    const uint32_t lead = (uint32_t)__builtin_amdgcn_readfirstlane((int)d1);
+                    const unsigned long long same = __builtin_amdgcn_ballot_w64(d1 == lead);
+                    if (d1 != lead) atomicAdd(&s_hist[1][d1], 1u);
+                    else if (lane == (int)__builtin_ctzll(same)) atomicAdd(&s_hist[1][lead], (uint32_t)__popcll(same));
+                }
+            }
         }
+    }
+    if (hist) {
+        __syncthreads();
+        const uint32_t c0 = s_hist[0][threadIdx.x], c1 = s_hist[1][threadIdx.x];
+        if (c0) atomicAdd(hist + threadIdx.x, c0);
+        if (c1) atomicAdd(hist + 256 + threadIdx.x, c1);
     }
 }
 
@@ -188,10 +273,12 @@ int launch_duplicate(const mgs_camera& cam, int P, const GeometryState& g, const
     uint32_t* zero_ptr = nullptr;
     size_t zero_words = 0;
     if (sort_n > 0) radix_zero_region(b.sort_temp, sort_n, sort_bits, &zero_ptr, &zero_words);
+    const bool count_digits = P > 0 && sort_bits <= 16 && radix_wants_hist(sort_n);
     hipLaunchKernelGGL(duplicate_kernel, dim3((n + 255) / 256), dim3(256), 0, s, P, g.rect_sorted, g.perm, g.point_offsets,
                        g.scan_blocks, b.keys_a, b.vals_a, tiles_x(cam.image_width), tiles_y(cam.image_height),
                        (uint32_t)(r_cap > 0xFFFFFFFFull ? 0xFFFFFFFFull : r_cap), n_touched, img.ranges, ntiles, zero_ptr,
-                       zero_words, count, overflow, depth_err);
+                       zero_words, count, overflow, depth_err, (P > 0 && scan_is_small(P)) ? 1 : 0,
+                       count_digits ? g.tile_hist : nullptr, (sort_bits + 7) / 8);
     MGS_HIP(hipGetLastError());
     return 0;
 }
@@ -208,9 +295,11 @@ int launch_depth_sort(const GeometryState& g, int P, hipStream_t s) {
                             g.rect, g.rect_sorted);
 }
 
-int launch_sort(const BinningState& b, uint64_t R, int bits, hipStream_t s, const uint32_t* n_dev) {
-    // the scratch was cleared by duplicate_kernel
-    return radix_sort_pairs(b.keys_a, b.vals_a, b.keys_b, b.vals_b, R, bits, b.sort_temp, s, n_dev, true);
+int launch_sort(const GeometryState& g, const BinningState& b, uint64_t R, int bits, hipStream_t s, const uint32_t* n_dev) {
+    // the scratch was cleared by duplicate_kernel, which also counted the digits of the keys it emitted (small sorts)
+    const bool counted = bits <= 16 && radix_wants_hist(R) && g.tile_hist != nullptr;
+    return radix_sort_pairs(b.keys_a, b.vals_a, b.keys_b, b.vals_b, R, bits, b.sort_temp, s, n_dev, true, nullptr, nullptr,
+                            counted ? g.tile_hist : nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------

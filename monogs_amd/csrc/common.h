@@ -132,12 +132,17 @@ struct GeometryState {
     uint2* rect;              // [P] tile rectangle {x0 | y0 << 16, w | h << 16} (w = h = 0: culled), by Gaussian index
     uint2* rect_sorted;       // [P] the same in depth order: written by the last pass of the depth sort, so that the
                               //     scan and duplicate read it coalesced instead of gathering through perm[]
-    void* sort_temp;          // depth sort scratch
+    uint64_t* scan_status;    // [SCAN_SMALL_MAX_BLOCKS] block totals of the single-launch scan (zeroed by preprocess)
+    uint32_t* tile_hist;      // [4][256] digit counts of the TILE sort's keys, counted by duplicate_kernel while it emits
+                              //          them (zeroed by preprocess; lives here because the binning scratch only exists
+                              //          once the instance count is known)
+    void* sort_temp;          // depth sort scratch (directly behind tile_hist: preprocess clears all three in one sweep)
     size_t sort_temp_bytes;
     char* end;                // one past the last carved byte
     static size_t bytes(int P);
     static GeometryState carve(void* base, int P);
 };
+constexpr int SCAN_SMALL_MAX_BLOCKS = 64;     // up to this many scan blocks (P <= 131 072) the scan is ONE launch
 
 struct ImageState {
     float* final_T;      // [H*W]
@@ -190,7 +195,12 @@ struct StageTimer;  // api.hip
 int launch_preprocess_forward(const mgs_camera& cam, int P, const float* means3D, const float* shs,
                               const float* colors_precomp, const float* opacities, const float* scales,
                               const float* rotations, const float* cov3D_precomp,
-                              const GeometryState& g, int32_t* radii, hipStream_t s);
+                              const GeometryState& g, int32_t* radii, float* prepare_grad_acc, hipStream_t s);
+// backward scratch: [grad_acc P x 16][pose-gradient slots TAU_SLOTS x 16][dL/dtau of a prepared backward: 16]
+constexpr int TAU_SLOTS = 256;              // one 64-byte line each
+inline float* backward_grad_acc(void* scratch) { return (float*)align_up((size_t)scratch, 256); }
+inline float* backward_tau_part(void* scratch, int P) { return backward_grad_acc(scratch) + (size_t)P * GRAD_FLOATS; }
+inline float* backward_tau_out(void* scratch, int P) { return backward_tau_part(scratch, P) + (size_t)TAU_SLOTS * 16; }
 int launch_scan(const GeometryState& g, int P, hipStream_t s);
 // `r_cap`: capacity of the binning buffers; `count` (device): [0] live instance count min(R, r_cap), [1] overflow flag
 int launch_duplicate(const mgs_camera& cam, int P, const GeometryState& g, const BinningState& b, uint64_t r_cap,
@@ -203,11 +213,16 @@ constexpr int RADIX_ERROR_WORDS = 4;      // = RS_MAX_PASSES (radix_sort.hip)
 const uint32_t* radix_error_flag(void* temp, uint64_t n, int bits);
 __device__ __forceinline__ uint32_t radix_failed(const uint32_t* __restrict__ e) { return (e[0] | e[1]) | (e[2] | e[3]); }
 void radix_zero_region(void* temp, uint64_t n, int bits, uint32_t** ptr, size_t* words);   // what must be 0 before a sort
+// `ext_hist` ([4][256], one-sweep path only): digit counts of the keys already counted by the kernel that produced them
+// -- the sort then launches no histogram kernel.  radix_wants_hist(n) tells the producer whether they will be used.
 int radix_sort_pairs(uint32_t* ka, uint32_t* va, uint32_t* kb, uint32_t* vb, uint64_t n, int bits, void* temp,
                      hipStream_t s, const uint32_t* n_dev = nullptr, bool temp_zeroed = false,
-                     const uint2* aux_in = nullptr, uint2* aux_out = nullptr);   // last pass also writes aux_out[i] = aux_in[value i]
+                     const uint2* aux_in = nullptr, uint2* aux_out = nullptr,   // last pass also writes aux_out[i] = aux_in[value i]
+                     const uint32_t* ext_hist = nullptr);
+bool radix_wants_hist(uint64_t n);
 int launch_depth_sort(const GeometryState& g, int P, hipStream_t s);
-int launch_sort(const BinningState& b, uint64_t R, int bits, hipStream_t s, const uint32_t* n_dev = nullptr);
+int launch_sort(const GeometryState& g, const BinningState& b, uint64_t R, int bits, hipStream_t s,
+                const uint32_t* n_dev = nullptr);
 int launch_ranges(const BinningState& b, uint64_t R, const ImageState& img, int ntiles, int sort_bits, hipStream_t s,
                   const uint32_t* n_dev = nullptr, uint32_t* status = nullptr);
 int set_radix_spin_limit(uint32_t limit);
@@ -228,7 +243,6 @@ struct GeomBackwardArgs {
         *dL_drotations, *dL_dtau;
     float* tau_part;         // [TAU_SLOTS][16] zeroed partial pose gradients (large launches), or NULL: add into dL_dtau directly
 };
-constexpr int TAU_SLOTS = 256;              // one 64-byte line each
 constexpr int TAU_DIRECT_MAX_BLOCKS = 256;  // up to this many workgroups the direct same-address adds are cheaper than a launch
 int launch_geom_backward(const mgs_camera& cam, int P, const GeometryState& g, const GeomBackwardArgs& a,
                          hipStream_t s);

@@ -27,11 +27,45 @@ struct PoseStepArgs {
     int step;             // 1-based Adam step count of this update (used when step_dev is NULL)
     int* step_dev;        // optional device counter: incremented here, so a captured graph replays correctly
     int flags;            // MGS_POSE_STICKY: once out[0] says converged, later calls change nothing
+    // optional: the camera tensors of this viewpoint, recomputed from the new R, T right here -- the next render of a loop
+    // then needs no camera_setup launch (the two kernels share camera_entry: same bits)
+    const float* proj_T;
+    float *view_T, *full_T, *campos;
 };
 
 __device__ __forceinline__ void mat3mul(const float* A, const float* B, float* C) {
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) C[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+}
+
+// Camera matrices of one viewpoint in ONE launch: what the reference assembles per render() from R, T with
+// getWorld2View + transpose, a 4x4 bmm and a 4x4 inverse
+// (/root/reference/gaussian_splatting/utils/graphics_utils.py:33-42, /root/reference/utils/camera_utils.py:171-178,
+// /root/reference/gaussian_splatting/gaussian_renderer/__init__.py:61-68) -- about ten small kernels in PyTorch.
+// All matrices are the TRANSPOSED (row-vector) ones the rasteriser takes.
+// Entry t of the 35 outputs (16 view, 16 full projection, 3 camera centre), with the products contracted explicitly:
+// camera_setup_kernel (one thread per entry) and pose_step_kernel (its one thread, all entries) give the same bits.
+__device__ __forceinline__ void camera_entry(const float* R, const float* T, const float* proj_T, int t, float* view_T,
+                                             float* full_T, float* campos) {
+    auto vT = [&](int i, int k) -> float {          // view_T[i][k] = W2C[k][i],  W2C = [[R, t], [0, 1]]
+        if (k < 3) return i < 3 ? R[3 * k + i] : T[k];
+        return i == 3 ? 1.f : 0.f;
+    };
+    if (t < 16) {
+        const int i = t >> 2, j = t & 3;
+        view_T[t] = vT(i, j);
+        float acc = 0.f;
+        for (int k = 0; k < 4; ++k) acc = __builtin_fmaf(vT(i, k), proj_T[4 * k + j], acc);
+        full_T[t] = acc;
+    } else if (t < 19) {
+        const int i = t - 16;                       // camera centre -R^T t
+        campos[i] = -__builtin_fmaf(R[6 + i], T[2], __builtin_fmaf(R[3 + i], T[1], R[i] * T[0]));
+    }
+}
+__global__ void camera_setup_kernel(const float* __restrict__ R, const float* __restrict__ T,
+                                    const float* __restrict__ proj_T, float* __restrict__ view_T,
+                                    float* __restrict__ full_T, float* __restrict__ campos) {
+    camera_entry(R, T, proj_T, (int)threadIdx.x, view_T, full_T, campos);
 }
 
 __global__ void pose_step_kernel(PoseStepArgs a) {
@@ -96,30 +130,10 @@ __global__ void pose_step_kernel(PoseStepArgs a) {
     a.out[1] = tn;
     if (a.host_flag) a.host_flag[0] = a.out[0];
     for (int i = 0; i < 3; ++i) { a.rot_delta[i] = 0.f; a.trans_delta[i] = 0.f; }
-}
-
-// Camera matrices of one viewpoint in ONE launch: what the reference assembles per render() from R, T with
-// getWorld2View + transpose, a 4x4 bmm and a 4x4 inverse
-// (/root/reference/gaussian_splatting/utils/graphics_utils.py:33-42, /root/reference/utils/camera_utils.py:171-178,
-// /root/reference/gaussian_splatting/gaussian_renderer/__init__.py:61-68) -- about ten small kernels in PyTorch.
-// All matrices are the TRANSPOSED (row-vector) ones the rasteriser takes.
-__global__ void camera_setup_kernel(const float* __restrict__ R, const float* __restrict__ T,
-                                    const float* __restrict__ proj_T, float* __restrict__ view_T,
-                                    float* __restrict__ full_T, float* __restrict__ campos) {
-    const int t = threadIdx.x;
-    auto vT = [&](int i, int k) -> float {          // view_T[i][k] = W2C[k][i],  W2C = [[R, t], [0, 1]]
-        if (k < 3) return i < 3 ? R[3 * k + i] : T[k];
-        return i == 3 ? 1.f : 0.f;
-    };
-    if (t < 16) {
-        const int i = t >> 2, j = t & 3;
-        view_T[t] = vT(i, j);
-        float acc = 0.f;
-        for (int k = 0; k < 4; ++k) acc += vT(i, k) * proj_T[4 * k + j];
-        full_T[t] = acc;
-    } else if (t < 19) {
-        const int i = t - 16;                       // camera centre -R^T t
-        campos[i] = -(R[i] * T[0] + R[3 + i] * T[1] + R[6 + i] * T[2]);
+    if (a.view_T) {
+        float Tn[3];
+        for (int i = 0; i < 3; ++i) Tn[i] = a.T[i];
+        for (int t = 0; t < 19; ++t) camera_entry(Rn, Tn, a.proj_T, t, a.view_T, a.full_T, a.campos);
     }
 }
 
@@ -141,17 +155,23 @@ extern "C" int mgs_pose_step(float* R, float* T, float* rot_delta, float* trans_
                              const float* grad_b, float* adam_m, float* adam_v, int32_t step, float lr_rot,
                              float lr_trans, float lr_exposure, float beta1, float beta2, float eps,
                              float converged_threshold, int32_t* step_counter, float* out, int32_t flags,
-                             float* host_flag, void* stream) {
+                             float* host_flag, const float* projmatrix_raw, float* viewmatrix, float* projmatrix,
+                             float* campos, void* stream) {
     if (!R || !T || !rot_delta || !trans_delta || !adam_m || !adam_v || !out) {
         set_error("R, T, rot_delta, trans_delta, adam_m, adam_v, out must be non-NULL");
         return 1;
     }
     if (!step_counter && step < 1) { set_error("step is 1-based"); return 1; }
+    if (viewmatrix && (!projmatrix_raw || !projmatrix || !campos)) {
+        set_error("camera refresh needs projmatrix_raw, viewmatrix, projmatrix and campos");
+        return 1;
+    }
     PoseStepArgs a;
     a.R = R; a.T = T; a.rot_delta = rot_delta; a.trans_delta = trans_delta; a.exp_a = exposure_a; a.exp_b = exposure_b;
     a.g_rot = grad_rot; a.g_trans = grad_trans; a.g_a = grad_a; a.g_b = grad_b; a.m = adam_m; a.v = adam_v; a.out = out;
     a.lr_rot = lr_rot; a.lr_trans = lr_trans; a.lr_exp = lr_exposure; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
     a.converged_threshold = converged_threshold; a.step = step; a.step_dev = step_counter; a.flags = flags; a.host_flag = host_flag;
+    a.proj_T = projmatrix_raw; a.view_T = viewmatrix; a.full_T = projmatrix; a.campos = campos;
     hipLaunchKernelGGL(pose_step_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a);
     MGS_HIP(hipGetLastError());
     return 0;

@@ -174,6 +174,8 @@ struct PreArgs {
     int rot_aligned16;        // rotations may be read with 16-byte loads
     uint32_t* zero_ptr;       // scratch of the depth sort that follows: cleared here instead of by its own launch
     size_t zero_words;
+    float* grad_acc;          // optional: accumulator of the backward that will follow ([P][16] + pose slots + 16): the
+                              //           lines of the visible Gaussians and the pose part are cleared here
 };
 
 // 16-byte per-lane loads where the caller's tensor allows it (torch allocations are 256-byte aligned; a sliced view may not be)
@@ -282,6 +284,10 @@ template <bool COV, bool PRECOMP>
 __global__ void __launch_bounds__(256) preprocess_forward_kernel(PreArgs a) {
     const int idx = blockIdx.x * 256 + threadIdx.x;        // (launched with 256 threads; blockDim would be a packet fetch)
     grid_zero(a.zero_ptr, a.zero_words, (size_t)((a.P + 255) / 256) * 256, 256);
+    if (a.grad_acc && blockIdx.x == 0) {              // pose-gradient slots + the six output floats: (TAU_SLOTS + 1) lines
+        float4* t4 = reinterpret_cast<float4*>(a.grad_acc + (size_t)a.P * GRAD_FLOATS);
+        for (int i = threadIdx.x; i < (TAU_SLOTS + 1) * 4; i += 256) t4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     if (idx >= a.P) return;
     // ---- every per-Gaussian input is requested up front: ONE memory round trip before the arithmetic starts (a load
     //      placed behind each early exit used to cost a dependent round trip of its own; the 32 bytes this reads for a
@@ -322,17 +328,36 @@ __global__ void __launch_bounds__(256) preprocess_forward_kernel(PreArgs a) {
         float4* rec = reinterpret_cast<float4*>(a.rec + (size_t)idx * REC_FLOATS);
         rec[0] = o.r0; rec[1] = o.r1; rec[2] = o.r2; rec[3] = o.r3;
     }
+    if (a.grad_acc) {
+        // The blend backward adds into the 64-byte gradient line of a visible Gaussian and the per-Gaussian backward reads
+        // it: those lines (only) are cleared here.  A full wave clears its 64 lines together -- lane l writes 16 bytes of
+        // the lines (l >> 2) + 16 k, k = 0..3, so each store instruction covers one contiguous KB minus the invisible
+        // Gaussians' holes (a lane writing its own line issued four 16-byte stores 64 bytes apart: +40 us at 2 M).
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int lane = threadIdx.x & 63, wave_first = idx - lane;
+        if (wave_first + WAVE <= a.P) {                       // wave-uniform: every lane is here
+            const unsigned long long vm = __builtin_amdgcn_ballot_w64(vis);
+            float4* base = reinterpret_cast<float4*>(a.grad_acc + (size_t)wave_first * GRAD_FLOATS);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if ((vm >> ((lane >> 2) + 16 * k)) & 1ull) base[k * WAVE + lane] = z4;
+        } else if (vis) {
+            float4* ga = reinterpret_cast<float4*>(a.grad_acc + (size_t)idx * GRAD_FLOATS);
+            ga[0] = z4; ga[1] = z4; ga[2] = z4; ga[3] = z4;
+        }
+    }
 }
 
 int launch_preprocess_forward(const mgs_camera& cam, int P, const float* means3D, const float* shs,
                               const float* colors_precomp, const float* opacities, const float* scales,
                               const float* rotations, const float* cov3D_precomp, const GeometryState& g,
-                              int32_t* radii, hipStream_t s) {
+                              int32_t* radii, float* prepare_grad_acc, hipStream_t s) {
     PreArgs a;
     a.means3D = means3D; a.shs = shs; a.colors = colors_precomp; a.opacities = opacities;
     a.scales = scales; a.rotations = rotations; a.cov3D = cov3D_precomp;
     a.V = cam.viewmatrix; a.PM = cam.projmatrix; a.campos = cam.campos;
     a.rec = g.rec; a.depth_key = g.depth_key; a.iota = g.iota;
+    a.grad_acc = prepare_grad_acc;
     a.rot_aligned16 = rotations && ((size_t)rotations % 16 == 0);
     a.clamped = g.clamped; a.rect = g.rect; a.radii = radii;
     a.tanfovx = cam.tanfovx; a.tanfovy = cam.tanfovy;
@@ -344,6 +369,9 @@ int launch_preprocess_forward(const mgs_camera& cam, int P, const float* means3D
     a.gx = tiles_x(a.W); a.gy = tiles_y(a.H); a.deg = cam.sh_degree; a.M = cam.sh_coeffs;
     if (P == 0) return 0;
     radix_zero_region(g.sort_temp, (uint64_t)P, 32, &a.zero_ptr, &a.zero_words);
+    // + the two small tables carved right in front of it (scan status words, tile-sort digit counts)
+    a.zero_words += (size_t)((char*)a.zero_ptr - (char*)g.scan_status) / 4;
+    a.zero_ptr = (uint32_t*)g.scan_status;
     const dim3 grid((P + 255) / 256), block(256);
     if (cov3D_precomp && colors_precomp) hipLaunchKernelGGL((preprocess_forward_kernel<true, true>), grid, block, 0, s, a);
     else if (cov3D_precomp) hipLaunchKernelGGL((preprocess_forward_kernel<true, false>), grid, block, 0, s, a);

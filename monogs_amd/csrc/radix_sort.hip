@@ -51,7 +51,12 @@ constexpr uint64_t RS_COUNT_MASK = (1ull << 62) - 1;
 constexpr uint32_t RS_SPIN_LIMIT = 1u << 22;
 // the bound actually used by the look-back spin: a device word so that a test can shrink it (mgs_debug_set_radix_spin_limit)
 __device__ uint32_t g_rs_spin_limit = RS_SPIN_LIMIT;
-constexpr int RS_WINDOW = 16;                     // predecessor status words fetched per look-back step
+// predecessor status words fetched per look-back step.  (Measured, round 2: wider windows for the small sorts -- 64 words
+// for the 40-tile depth sort of a 40 k map, 32 for the 200-tile tile sort -- on the theory that the look-back is a chain
+// of round trips: 12.5-14 us per pass instead of 9.2-10.7, 15.6-16.3 instead of 14.1-14.3.  Most predecessors have
+// already published their inclusive count when a tile looks back; the extra loads and the longer consume loop only cost.
+//  Narrower windows, 8 and 4 words: 52.9 / 53.4 us against 56.2 us for the depth sort at 100 k -- inside the noise.)
+constexpr int RS_WINDOW = 16;
 
 // large sorts take the SCANNED path (rs_pass_kernel); a test knob forces either one (no environment lookups on the launch path)
 int g_opt_radix_scanned = -1;       // mgs_debug_set_option("radix_scanned", -1 | 0 | 1): -1 = by size
@@ -209,7 +214,7 @@ struct RsPassArgs {
 //                  rs_scan_kernel.  With several hundred co-resident tiles starting together the look-back reads
 //                  ~tiles^2/2 x 256 status words per pass -- more L2 traffic than the keys -- and its chain of
 //                  round trips, not the data movement, set the pass time (35 us for 32 MB at 2 M pairs).
-template <int ITEMS, bool SCANNED>
+template <int ITEMS, bool SCANNED, int WINDOW = RS_WINDOW>
 __global__ void __launch_bounds__(RS_THREADS) rs_pass_kernel(RsPassArgs a) {
     constexpr int TILE_PAIRS = RS_THREADS * ITEMS;
     __shared__ uint32_t wave_hist[RS_WAVES][RS_RADIX];
@@ -221,6 +226,7 @@ __global__ void __launch_bounds__(RS_THREADS) rs_pass_kernel(RsPassArgs a) {
     __shared__ uint32_t s_tile;
 
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const uint32_t hcount = a.hist[t];       // requested first: needed only after the ranking, one round trip hidden
     if (!SCANNED) {
         // A timed-out look-back in an EARLIER pass left part of this pass's input unwritten: ranking it against the
         // histogram of the original keys could place pairs past the end of the buffers.  Such a pass does nothing (the
@@ -292,7 +298,6 @@ __global__ void __launch_bounds__(RS_THREADS) rs_pass_kernel(RsPassArgs a) {
     digit_base[t] = dbase;
     // exclusive global base of digit t = scan of this pass's 256 digit totals (global histogram on the one-sweep path,
     // row totals of rs_row_scan_kernel on the SCANNED path): cheaper here than a separate launch
-    const uint32_t hcount = a.hist[t];
     const uint32_t hincl = wave_incl_scan_dpp(hcount);
     __syncthreads();                     // wsum is reused
     if (lane == 63) wsum[wv] = hincl;
@@ -319,9 +324,9 @@ __global__ void __launch_bounds__(RS_THREADS) rs_pass_kernel(RsPassArgs a) {
             bool found = false;
             uint32_t spins = 0;
             while (!found) {
-                uint64_t w[RS_WINDOW];
+                uint64_t w[WINDOW];
 #pragma unroll
-                for (int q = 0; q < RS_WINDOW; ++q) {
+                for (int q = 0; q < WINDOW; ++q) {
                     const int64_t jj = j - q;
                     w[q] = jj >= 0 ? __hip_atomic_load(a.status + (size_t)jj * RS_RADIX + t, __ATOMIC_RELAXED,
                                                        __HIP_MEMORY_SCOPE_AGENT)
@@ -329,7 +334,7 @@ __global__ void __launch_bounds__(RS_THREADS) rs_pass_kernel(RsPassArgs a) {
                 }
                 int used = 0;
 #pragma unroll
-                for (int q = 0; q < RS_WINDOW; ++q) {
+                for (int q = 0; q < WINDOW; ++q) {
                     if (!found && used == q) {
                         const uint64_t f = w[q] >> 62;
                         if (f != 0ull) {
@@ -401,8 +406,12 @@ void radix_zero_region(void* temp, uint64_t n, int bits, uint32_t** ptr, size_t*
     *words = rs_scanned(n) ? (size_t)((char*)t.status - (char*)t.hist) / 4 : t.zero_bytes / 4;
 }
 
+// does a sort of n pairs read a global digit histogram (one-sweep path) -- i.e. is it worth counting one while the keys are produced?
+bool radix_wants_hist(uint64_t n) { return n > 0 && !rs_scanned(n); }
+
 int radix_sort_pairs(uint32_t* ka, uint32_t* va, uint32_t* kb, uint32_t* vb, uint64_t n, int bits, void* temp,
-                     hipStream_t s, const uint32_t* n_dev, bool temp_zeroed, const uint2* aux_in, uint2* aux_out) {
+                     hipStream_t s, const uint32_t* n_dev, bool temp_zeroed, const uint2* aux_in, uint2* aux_out,
+                     const uint32_t* ext_hist) {
     if (n == 0) return 0;
     if (n >= (1ull << 32)) { set_error("radix sort: more than 2^32-1 pairs"); return 1; }
     const int npasses = rs_passes(bits);
@@ -412,15 +421,16 @@ int radix_sort_pairs(uint32_t* ka, uint32_t* va, uint32_t* kb, uint32_t* vb, uin
     const uint32_t tiles = rs_tiles(n);
     const uint32_t hist_blocks = min(tiles, 1024u);
     const bool scanned = rs_scanned(n);
-    if (!scanned)
+    if (!scanned && !ext_hist)
         hipLaunchKernelGGL(rs_hist_kernel, dim3(hist_blocks), dim3(RS_THREADS), 0, s, ka, (uint32_t)n, n_dev, npasses, t.hist);
+    const uint32_t* ghist = (!scanned && ext_hist) ? ext_hist : t.hist;
     uint32_t* counts = reinterpret_cast<uint32_t*>(t.status);      // the status words are unused on the SCANNED path
     uint32_t *kin = ka, *vin = va, *kout = kb, *vout = vb;
     for (int p = 0; p < npasses; ++p) {
         RsPassArgs a;
         a.kin = kin; a.kout = kout; a.vin = vin; a.vout = vout;
         a.n = (uint32_t)n; a.n_dev = n_dev; a.shift = 8 * p;
-        a.hist = t.hist + p * RS_RADIX;
+        a.hist = ghist + p * RS_RADIX;
         a.status = t.status + (size_t)p * tiles * RS_RADIX;
         // <= one workgroup per CU: the whole grid is co-resident whatever the dispatch order, so block ids are safe
         a.ticket = tiles <= 256u ? nullptr : t.tickets + p;

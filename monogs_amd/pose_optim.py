@@ -38,16 +38,23 @@ class PoseAdam:
             p.grad = None
 
     @torch.no_grad()
-    def step_and_retract(self, converged_threshold=1e-4, sync=True, host_flag=None):
+    def step_and_retract(self, converged_threshold=1e-4, sync=True, host_flag=None, camera=None):
         """Returns the convergence flag (bool) when ``sync`` else the device tensor out[2].  ``host_flag``: a PINNED
         host float tensor whose first element the kernel also writes the flag to (device stores into mapped host memory:
-        a loop replayed from a hipGraph then needs no device-to-host copy per iteration)."""
+        a loop replayed from a hipGraph then needs no device-to-host copy per iteration).  ``camera``: the viewpoint's
+        ``(projmatrix_raw, viewmatrix, projmatrix, campos)`` tensors (``camera.fused_camera_matrices``): the kernel
+        refreshes the last three from the updated pose, bit-identically to ``mgs_camera_setup``, so the next render of
+        the loop launches no camera kernel."""
         lib = _lib.load()
         vp = self.vp
         R = vp.R.contiguous() if not vp.R.is_contiguous() else vp.R
         T = vp.T.contiguous() if not vp.T.is_contiguous() else vp.T
         if R.data_ptr() != vp.R.data_ptr() or T.data_ptr() != vp.T.data_ptr():
             vp.R, vp.T = R, T
+        if camera is None:        # camera tensors cached on the viewpoint by render(): keep them current in the same launch
+            c = getattr(vp, "_mgs_cam", None)
+            if c is not None and c[0] is vp.R and c[1] is vp.T:
+                camera = (c[2],) + tuple(c[3])
         g = lambda p: None if p.grad is None else p.grad.contiguous().data_ptr()  # noqa: E731
         with _device_guard(R.device):
             _lib.check(lib.mgs_pose_step(R.data_ptr(), T.data_ptr(), vp.cam_rot_delta.data_ptr(),
@@ -57,6 +64,8 @@ class PoseAdam:
                                          0, self.lrs[0], self.lrs[1], self.lrs[2], self.betas[0], self.betas[1],
                                          self.eps, float(converged_threshold), self.t_dev.data_ptr(),
                                          self.out.data_ptr(), 1 if self.sticky else 0,
-                                         None if host_flag is None else host_flag.data_ptr(), _stream()),
+                                         None if host_flag is None else host_flag.data_ptr(),
+                                         *((None,) * 4 if camera is None else tuple(t.data_ptr() for t in camera)),
+                                         _stream()),
                        "mgs_pose_step")
         return bool(self.out[0].item() > 0.5) if sync else self.out

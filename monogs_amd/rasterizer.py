@@ -194,6 +194,12 @@ class _RasterizeGaussians(torch.autograd.Function):
             color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
             depth = torch.empty(1, H, W, dtype=torch.float32, device=dev)
             opacity = torch.empty(1, H, W, dtype=torch.float32, device=dev)
+            # The scratch of the backward that will follow is handed to the forward: its per-Gaussian kernel clears the
+            # gradient lines of the visible Gaussians (and the pose part) on the way, and the backward starts with no
+            # clearing launch and no 64 B x P fill.
+            ctx.scratch = (torch.empty(lib.mgs_backward_bytes(P), **u8)
+                           if (P > 0 and any(ctx.needs_input_grad)) else None)
+            ctx.scratch_used = False
             key = (P, W, H)
             capturing = torch.cuda.is_current_stream_capturing()
             hint = _capacity_hint.get(key)
@@ -205,7 +211,8 @@ class _RasterizeGaussians(torch.autograd.Function):
                 R = max(int(hint * _sync_free["headroom"]) + 4096, 4096)
                 _lib.check(lib.mgs_forward_preprocess(
                     C.byref(cam), P, _ptr(means3D), _ptr(sh_), _ptr(col_), _ptr(opac_), _ptr(sc_), _ptr(rot_),
-                    _ptr(cov_), geom.data_ptr(), radii.data_ptr(), None, tref, _stream()), "mgs_forward_preprocess")
+                    _ptr(cov_), geom.data_ptr(), radii.data_ptr(), _ptr(ctx.scratch), None, tref, _stream()),
+                    "mgs_forward_preprocess")
                 binning = torch.empty(lib.mgs_binning_bytes(R, W, H), **u8)
                 overflow = torch.empty(1, dtype=torch.int32, device=dev)      # written by the clamp kernel
                 _lib.check(lib.mgs_forward_render_capacity(
@@ -220,8 +227,8 @@ class _RasterizeGaussians(torch.autograd.Function):
                 num_rendered = C.c_uint64(0)
                 _lib.check(lib.mgs_forward_preprocess(
                     C.byref(cam), P, _ptr(means3D), _ptr(sh_), _ptr(col_), _ptr(opac_), _ptr(sc_), _ptr(rot_),
-                    _ptr(cov_), geom.data_ptr(), radii.data_ptr(), C.byref(num_rendered), tref, _stream()),
-                    "mgs_forward_preprocess")
+                    _ptr(cov_), geom.data_ptr(), radii.data_ptr(), _ptr(ctx.scratch), C.byref(num_rendered), tref,
+                    _stream()), "mgs_forward_preprocess")
                 R = int(num_rendered.value)
                 _capacity_hint[key] = R
                 binning = torch.empty(lib.mgs_binning_bytes(R, W, H), **u8)
@@ -290,8 +297,14 @@ class _RasterizeGaussians(torch.autograd.Function):
                 o += P * w
             d_means3D, d_col, d_opac, d_scales, d_rot = views
             want_tau = (need[8] and has_theta) or (need[9] and has_rho)
-            d_tau = torch.empty(6, **f32) if want_tau else None
-            scratch = torch.empty(lib.mgs_backward_bytes(P), dtype=torch.uint8, device=dev)
+            prepared = ctx.scratch is not None and not ctx.scratch_used      # (a second backward through the same forward
+            ctx.scratch_used = True                                          #  clears a fresh scratch with a launch)
+            scratch = ctx.scratch if prepared else torch.empty(lib.mgs_backward_bytes(P), dtype=torch.uint8, device=dev)
+            if want_tau and prepared:       # the six floats live inside the prepared scratch (the forward cleared them)
+                off = int(lib.mgs_backward_tau(scratch.data_ptr(), P)) - scratch.data_ptr()
+                d_tau = scratch[off:off + 24].view(torch.float32)
+            else:
+                d_tau = torch.empty(6, **f32) if want_tau else None
             timing = _lib.MgsTiming() if _timing_sink is not None else None
             tref = C.byref(timing) if timing is not None else None
             _lib.check(lib.mgs_backward(
@@ -301,7 +314,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 radii.data_ptr(), geom.data_ptr(), binning.data_ptr(), img.data_ptr(),
                 g_color.data_ptr(), g_depth.data_ptr(),
                 _ptr(d_means2D), _ptr(d_col), _ptr(d_opac), _ptr(d_means3D), _ptr(d_cov), _ptr(d_sh),
-                _ptr(d_scales), _ptr(d_rot), _ptr(d_tau), scratch.data_ptr(), tref, _stream()),
+                _ptr(d_scales), _ptr(d_rot), _ptr(d_tau), scratch.data_ptr(), 1 if prepared else 0, tref, _stream()),
                 "mgs_backward")
             if timing is not None:
                 d = timing.as_dict()

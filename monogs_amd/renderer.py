@@ -14,7 +14,7 @@ import math
 
 import torch
 
-from .camera import fused_camera_matrices
+from .camera import cached_camera_tensors
 from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
 
 
@@ -41,7 +41,8 @@ def render(viewpoint_camera, cam_intrinsics, means, rotations, scales, opacity, 
     if (torch.is_tensor(R) and torch.is_tensor(T) and R.is_cuda and T.is_cuda and R.shape == (3, 3) and T.shape == (3,)
             and projection_matrix.is_cuda):
         # the reference's camera objects carry R, T (utils/camera_utils.py:82-221): all three camera tensors in one launch
-        world_view, full_proj, campos = fused_camera_matrices(R, T, projection_matrix)
+        # (remembered on the camera object until R / T are replaced; the fused pose step keeps the cache current in place)
+        world_view, full_proj, campos = cached_camera_tensors(viewpoint_camera, R, T, projection_matrix)
     else:
         world_view = viewpoint_camera.world_view_transform
         full_proj = (world_view.unsqueeze(0).bmm(projection_matrix.unsqueeze(0))).squeeze(0)

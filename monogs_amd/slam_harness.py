@@ -122,6 +122,8 @@ class TrackingGraph:
         self.events = [torch.cuda.Event() for _ in range(2)]
         self.graph = None
         self.zero2d = torch.zeros_like(self.map[0])
+        # the static viewpoint's camera tensors: computed when a frame is loaded, then kept current by the pose step itself
+        self.cam3 = (torch.empty(4, 4, device=dev), torch.empty(4, 4, device=dev), torch.empty(3, device=dev))
         self._load(proto)
         keep = (self.svp.R.clone(), self.svp.T.clone(), self.svp.exposure_a.data.clone(), self.svp.exposure_b.data.clone())
         # eager warm-up on a side stream (also records the capacity hint for this map size), then capture
@@ -148,7 +150,7 @@ class TrackingGraph:
     def _iteration(self, host_flag=None):
         # render() without what tracking never reads: no screen-space gradient holder, no visibility filter
         xyz, rot, sca3, opa, col = self.map
-        view, full, campos = cam.fused_camera_matrices(self.svp.R, self.svp.T, self.intr.projection_matrix)
+        view, full, campos = self.cam3
         rs = GaussianRasterizationSettings(
             image_height=int(self.intr.height), image_width=int(self.intr.width),
             tanfovx=math.tan(self.intr.FoVx * 0.5), tanfovy=math.tan(self.intr.FoVy * 0.5), bg=self.bg, scale_modifier=1.0,
@@ -162,7 +164,7 @@ class TrackingGraph:
         # the scalar (its finalize kernel and the ones-fill of loss.backward() were two of the 25 launches of a replay)
         lg = fused_losses.loss_grads(color, depth, opacity, self.svp, tracking=True)
         lg.backward(color, depth, self.svp)
-        self.opt.step_and_retract(sync=False, host_flag=host_flag)
+        self.opt.step_and_retract(sync=False, host_flag=host_flag, camera=(self.intr.projection_matrix,) + self.cam3)
 
     @torch.no_grad()
     def _load(self, vp: Viewpoint):
@@ -171,6 +173,7 @@ class TrackingGraph:
         s.R.copy_(vp.R); s.T.copy_(vp.T)
         s.exposure_a.data.copy_(vp.exposure_a.data); s.exposure_b.data.copy_(vp.exposure_b.data)
         s.cam_rot_delta.data.zero_(); s.cam_trans_delta.data.zero_()
+        cam.fused_camera_matrices(s.R, s.T, self.intr.projection_matrix, out=self.cam3)
         self.opt.reset()
         for f in self.flags:          # (host words; nothing is in flight between two frames)
             f.zero_()

@@ -208,6 +208,29 @@ def test_multiple_forwards_before_one_backward(native_lib):
     assert ((means.grad.cpu() - ref).norm() / ref.norm()).item() < 1e-3
 
 
+def test_second_backward_through_one_forward(native_lib):
+    """The forward prepares (clears) the scratch of ONE backward; a second backward through the same forward
+    (retain_graph=True) must take the clearing path and give the same gradients, pose gradient included."""
+    from monogs_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+    sc = make_scene(4000, "fr3_office", seed=77)
+    leaf = lambda t: t.to(DEV).clone().requires_grad_(True)  # noqa: E731
+    means, opa, col, rot, scales = leaf(sc.means3D), leaf(sc.opacities), leaf(sc.colors), leaf(sc.rotations), leaf(sc.scales)
+    theta, rho = torch.zeros(3, device=DEV, requires_grad=True), torch.zeros(3, device=DEV, requires_grad=True)
+    st = scene_settings(sc, GaussianRasterizationSettings, device=DEV)
+    out = GaussianRasterizer(st)(means3D=means, means2D=torch.zeros_like(means), opacities=opa, colors_precomp=col,
+                                 scales=scales, rotations=rot, theta=theta, rho=rho)
+    loss = (out[0] * sc.grad_color.to(DEV)).sum() + (out[2] * sc.grad_depth.to(DEV)).sum()
+    leaves = (means, opa, col, rot, scales, theta, rho)
+    loss.backward(retain_graph=True)
+    first = [t.grad.clone() for t in leaves]
+    for t in leaves:
+        t.grad = None
+    loss.backward()
+    for a, t in zip(first, leaves):
+        assert a.abs().max() > 0
+        assert ((t.grad - a).norm() / a.norm()).item() < 1e-5        # (float atomics: the order of the adds differs)
+
+
 def test_capacity_mode_matches_exact_path(native_lib):
     """Sync-free forward (device-side instance count, capacity-sized scratch) gives the same images and
     gradients as the exact path; an under-sized capacity raises the overflow flag instead of writing out of bounds."""

@@ -8,7 +8,13 @@ rows = list(csv.DictReader(open(path)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 idx = [i for i, r in enumerate(rows) if marker in r["Kernel_Name"]]
 k = int(sys.argv[3]) if len(sys.argv) > 3 else -1     # which occurrence ends the window (default: the last)
-a, b = idx[k - 1], idx[k]
+must = sys.argv[4] if len(sys.argv) > 4 else None      # optional: the window must contain a kernel with this substring
+if must:                                                # ... then the k-th such window counts
+    wins = [(idx[j - 1], idx[j]) for j in range(1, len(idx))
+            if any(must in r["Kernel_Name"] for r in rows[idx[j - 1] + 1:idx[j] + 1])]
+    a, b = wins[k]
+else:
+    a, b = idx[k - 1], idx[k]
 t0 = int(rows[a]["End_Timestamp"])
 for r in rows[a + 1:b + 1]:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])

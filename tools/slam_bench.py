@@ -29,6 +29,7 @@ if __name__ == "__main__":
     ap.add_argument("--eager-mapping", action="store_true", help="with --graph: capture tracking only")
     ap.add_argument("--torch-pose", action="store_true", help="torch.optim.Adam + Python retraction instead of mgs_pose_step")
     ap.add_argument("--torch-losses", action="store_true", help="use the plain PyTorch losses instead of the fused HIP ones")
+    ap.add_argument("--serial-kf", action="store_true", help="render the window's keyframes one after the other (default with --graph: a stream each)")
     ap.add_argument("--lookahead", type=int, default=1, choices=[0, 1],
                     help="with --graph: read the convergence flag of tracking iteration n-1 while n runs")
     a = ap.parse_args()
@@ -40,7 +41,7 @@ if __name__ == "__main__":
     if a.mapping_iters is not None:
         cfg["mapping_itr_num"] = a.mapping_iters
     out = run_slam(n_frames=a.frames, init_itr_num=a.init_iters, n_gaussians=a.gaussians,
-                   fused_losses_on=not a.torch_losses, fused_pose_on=not a.torch_pose, graph_tracking=a.graph, graph_mapping=a.graph and not a.eager_mapping, track_lookahead=a.lookahead, loss_module=loss_module,
+                   fused_losses_on=not a.torch_losses, fused_pose_on=not a.torch_pose, graph_tracking=a.graph, graph_mapping=a.graph and not a.eager_mapping, track_lookahead=a.lookahead, loss_module=loss_module, parallel_keyframes=False if a.serial_kf else None,
                    log=lambda s: print("[slam]", s, file=sys.stderr, flush=True), **cfg)
     out["workload"] = f"synthetic {a.config}-like sequence, {a.frames} frames"
     for k in ("poses", "camera_centers", "camera_centers_gt"):      # tensors: not JSON

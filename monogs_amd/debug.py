@@ -16,8 +16,9 @@ def _au(v, a=256):
 
 
 def forward_tables(rs, means3D, opacities, colors_precomp=None, shs=None, scales=None, rotations=None,
-                   cov3D_precomp=None):
-    """Run the HIP forward and return outputs plus the per-tile tables as torch tensors."""
+                   cov3D_precomp=None, between=None):
+    """Run the HIP forward and return outputs plus the per-tile tables as torch tensors.  ``between``: called after the
+    first stage (per-Gaussian kernel, depth sort, scan) has finished and before the second (duplicate, tile sort, blend) starts."""
     lib = _lib.load()
     dev = means3D.device
     P = means3D.shape[0]
@@ -43,10 +44,14 @@ def forward_tables(rs, means3D, opacities, colors_precomp=None, shs=None, scales
                                               geom.data_ptr(), radii.data_ptr(), None, C.byref(nr), None, _stream()),
                    "mgs_forward_preprocess")
         R = int(nr.value)
+        if between is not None:
+            between()
         binning = torch.zeros(lib.mgs_binning_bytes(R, W, H), **u8)
+        status = torch.zeros(1, dtype=torch.int32, device=dev)
         _lib.check(lib.mgs_forward_render(C.byref(cam), P, R, geom.data_ptr(), binning.data_ptr(), img.data_ptr(),
                                           color.data_ptr(), depth.data_ptr(), opacity.data_ptr(),
-                                          n_touched.data_ptr(), None, None, _stream()), "mgs_forward_render")
+                                          n_touched.data_ptr(), status.data_ptr() if P > 0 else None, None, _stream()),
+                   "mgs_forward_render")
         torch.cuda.synchronize()
 
     def view(buf, off, nbytes, dtype):
@@ -74,5 +79,6 @@ def forward_tables(rs, means3D, opacities, colors_precomp=None, shs=None, scales
     tiles_touched = (wh & 0xFFFF) * ((wh >> 16) & 0xFFFF)           # tiles each Gaussian touches = w * h of its rectangle
     depth_key = rec[:, 11].contiguous().view(torch.int32)          # float32 bits of the view-space depth
     return dict(color=color, depth=depth, opacity=opacity, radii=radii, n_touched=n_touched, num_rendered=R,
+                status=int(status.item()),
                 final_T=final_T, n_contrib=n_contrib, ranges=ranges, tile_sorted=tile_sorted,
                 point_list=point_list, rec=rec, tiles_touched=tiles_touched, depth_key=depth_key, perm=perm)

@@ -306,6 +306,30 @@ def test_radix_lookback_timeout_is_reported_in_every_mode(native_lib):
     assert torch.equal(out[0], ref[0])
 
 
+def test_tile_sort_timeout_raises_its_own_status_bit_and_blends_nothing(native_lib):
+    """A look-back timeout in the TILE sort (the depth sort healthy): the status word carries MGS_STATUS_TILE_SORT_TIMEOUT,
+    the tile ranges stay empty and nothing is blended -- no instance index is ever read from the half-written list."""
+    from monogs_amd import _lib
+    from monogs_amd.debug import forward_tables
+    lib = _lib.load()
+    sc = make_scene(60000, "fr3_office", seed=5)
+    st = _hip_st(sc)
+    dev = lambda t: t.to(DEV)  # noqa: E731
+    args = dict(colors_precomp=dev(sc.colors), scales=dev(sc.scales), rotations=dev(sc.rotations))
+    lib.mgs_debug_set_option(b"radix_scanned", 0)         # one-sweep tile sort whatever the instance count
+    try:
+        good = forward_tables(st, dev(sc.means3D), dev(sc.opacities), **args)
+        assert good["status"] == 0 and float(good["opacity"].max()) > 0.5 and good["num_rendered"] > 8192
+        bad = forward_tables(st, dev(sc.means3D), dev(sc.opacities), **args,
+                             between=lambda: lib.mgs_debug_set_radix_spin_limit(0))
+    finally:
+        lib.mgs_debug_set_radix_spin_limit(0xFFFFFFFF)
+        lib.mgs_debug_set_option(b"radix_scanned", -1)
+    assert bad["status"] == 4                             # MGS_STATUS_TILE_SORT_TIMEOUT only: the depth sort had finished
+    assert float(bad["opacity"].abs().max()) == 0.0 and int(bad["n_contrib"].max()) == 0
+    assert int(bad["ranges"].abs().max()) == 0
+
+
 def test_streams_nograd_and_noncontiguous_inputs(native_lib):
     """The library launches on the caller's current stream, works under no_grad, with inputs that do not
     require grad and with non-contiguous views (made contiguous at the boundary, as upstream's .contiguous())."""

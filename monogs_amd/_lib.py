@@ -97,6 +97,12 @@ def load():
         fn.argtypes = args
     if lib.mgs_abi_version() != ABI_VERSION:
         raise MonoGSNativeError(f"ABI mismatch: library {lib.mgs_abi_version()} vs binding {ABI_VERSION}; rebuild")
+    # measurement knobs for A/B runs of whole programs (tools/, bench.py): MGS_DEBUG_OPTIONS="name=value,name=value"
+    # -> mgs_debug_set_option at load time (read here, once; nothing on the launch path consults the environment)
+    for kv in filter(None, os.environ.get("MGS_DEBUG_OPTIONS", "").split(",")):
+        k, _, v = kv.partition("=")
+        if lib.mgs_debug_set_option(k.strip().encode(), int(v)) != 0:
+            raise MonoGSNativeError(f"MGS_DEBUG_OPTIONS: {lib.mgs_last_error().decode()}")
     _lib = lib
     return lib
 

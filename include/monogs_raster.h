@@ -296,6 +296,11 @@ int mgs_activate_backward(int32_t P, int32_t scale_dim, const float* rot_raw, co
                           const float* grad_opacities, float* d_rot_raw, float* d_scale_raw, float* d_opacity_raw,
                           void* stream);
 
+/* dst[i] = src_0[i] + src_1[i] + ... (1..16 device buffers of `count` floats, `src` a HOST array of device pointers; dst may
+ * be one of the sources): the gradients that the N keyframe renders of a mapping window return for the same map tensor,
+ * summed in ONE launch instead of the autograd engine's N - 1 pairwise adds per tensor (monogs_amd.window.fan_out). */
+int mgs_sum_buffers(int32_t n_src, const float* const* src, float* dst, uint64_t count, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -68,6 +68,7 @@ SIGNATURES = {
                       + [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p] + [C.c_void_p] * 4 + [C.c_void_p]),
     "mgs_adam_step": (C.c_int, [C.c_int32] + [C.c_void_p] * 6 + [C.c_double] * 3 + [C.c_int32, C.c_void_p, C.c_void_p]),
     "mgs_densify_stats": (C.c_int, [C.c_int32] + [C.c_void_p] * 6),
+    "mgs_sum_buffers": (C.c_int, [C.c_int32, C.POINTER(C.c_void_p), C.c_void_p, C.c_uint64, C.c_void_p]),
     "mgs_activate_forward": (C.c_int, [C.c_int32, C.c_int32] + [C.c_void_p] * 7),
     "mgs_activate_backward": (C.c_int, [C.c_int32, C.c_int32] + [C.c_void_p] * 10),
     "mgs_knn_scratch_bytes": (C.c_size_t, [C.c_int32]),

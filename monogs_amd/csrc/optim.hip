@@ -227,3 +227,66 @@ int mgs_activate_backward(int32_t P, int32_t scale_dim, const float* rot_raw, co
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// dst[i] = sum_k src_k[i]: the gradients that the N keyframe renders of a mapping window return for the SAME map tensor,
+// added up in ONE launch (autograd's engine adds them pairwise: N - 1 launches per shared tensor, ~20 per iteration for a
+// window of four -- /root/reference/utils/slam_mapper.py:273-394 sums the losses and calls backward once).
+// The order of the adds is fixed (k = 0, 1, ...): bitwise reproducible.
+// ------------------------------------------------------------------------------------------------
+namespace mgs {
+constexpr int SUM_MAX_SRC = 16;
+struct SumArgs {
+    const float* src[SUM_MAX_SRC];
+    float* dst;
+    size_t count;
+    int n, vec;
+};
+__global__ void __launch_bounds__(256) sum_buffers_kernel(SumArgs a) {
+    const size_t i0 = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256;
+    if (a.vec) {
+        const size_t nv = a.count / 4;
+        for (size_t i = i0; i < nv; i += stride) {
+            float4 acc = reinterpret_cast<const float4*>(a.src[0])[i];
+            for (int k = 1; k < a.n; ++k) {
+                const float4 v = reinterpret_cast<const float4*>(a.src[k])[i];
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+            reinterpret_cast<float4*>(a.dst)[i] = acc;
+        }
+        for (size_t i = nv * 4 + i0; i < a.count; i += stride) {
+            float acc = a.src[0][i];
+            for (int k = 1; k < a.n; ++k) acc += a.src[k][i];
+            a.dst[i] = acc;
+        }
+    } else {
+        for (size_t i = i0; i < a.count; i += stride) {
+            float acc = a.src[0][i];
+            for (int k = 1; k < a.n; ++k) acc += a.src[k][i];
+            a.dst[i] = acc;
+        }
+    }
+}
+}  // namespace mgs
+
+extern "C" int mgs_sum_buffers(int32_t n_src, const float* const* src /* host array of device pointers */, float* dst,
+                               uint64_t count, void* stream) {
+    using namespace mgs;
+    if (n_src < 1 || n_src > SUM_MAX_SRC || !src || !dst) { set_error("mgs_sum_buffers: 1..16 sources, non-NULL pointers"); return 1; }
+    if (count == 0) return 0;
+    SumArgs a;
+    bool vec = ((size_t)dst % 16) == 0;
+    for (int k = 0; k < n_src; ++k) {
+        if (!src[k]) { set_error("mgs_sum_buffers: NULL source"); return 1; }
+        a.src[k] = src[k];
+        vec = vec && ((size_t)src[k] % 16) == 0;
+    }
+    for (int k = n_src; k < SUM_MAX_SRC; ++k) a.src[k] = nullptr;
+    a.dst = dst; a.count = (size_t)count; a.n = n_src; a.vec = vec ? 1 : 0;
+    const size_t items = vec ? (count + 3) / 4 : count;
+    size_t blocks = (items + 255) / 256;
+    blocks = blocks > 2048 ? 2048 : blocks;
+    hipLaunchKernelGGL(sum_buffers_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    MGS_HIP(hipGetLastError());
+    return 0;
+}

@@ -159,6 +159,91 @@ class _Activate(torch.autograd.Function):
         return d_rot, d_scale, d_opac
 
 
+def sum_buffers(srcs, out=None):
+    """``out = srcs[0] + srcs[1] + ...`` (contiguous float32 device tensors of one size) in ONE launch (``mgs_sum_buffers``;
+    more than 16 sources: groups of 16, the running sum first).  The order of the adds is fixed."""
+    lib = _lib.load()
+    srcs = list(srcs)
+    if out is None:
+        out = torch.empty_like(srcs[0])
+    grp, rest = srcs[:16], srcs[16:]
+    with _device_guard(out.device):
+        while True:
+            arr = (C.c_void_p * len(grp))(*[t.data_ptr() for t in grp])
+            _lib.check(lib.mgs_sum_buffers(len(grp), arr, out.data_ptr(), out.numel(), _stream()), "mgs_sum_buffers")
+            if not rest:
+                break
+            grp, rest = [out] + rest[:15], rest[15:]
+    return out
+
+
+class _FanOut(torch.autograd.Function):
+    """n aliases of each of m tensors; backward adds the n incoming gradients of every tensor in one launch."""
+
+    @staticmethod
+    def forward(ctx, n, *tensors):
+        ctx.n, ctx.m = int(n), len(tensors)
+        ctx.set_materialize_grads(False)
+        return tuple(t.view_as(t) for _ in range(int(n)) for t in tensors)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        n, m = ctx.n, ctx.m
+        per = [grads[k * m:(k + 1) * m] for k in range(n)]
+        ok = lambda g: g is not None and g.dtype == torch.float32 and g.is_contiguous()  # noqa: E731
+
+        def flat_of(gs):            # the m gradients of one consumer as ONE buffer, if they lie back to back
+            if not all(ok(g) for g in gs):
+                return None
+            end = gs[0].data_ptr()
+            for g in gs:
+                if g.data_ptr() != end:
+                    return None
+                end += g.numel() * 4
+            st = gs[0].untyped_storage()
+            if any(g.untyped_storage().data_ptr() != st.data_ptr() for g in gs):
+                return None
+            total = sum(g.numel() for g in gs)
+            return torch.as_strided(gs[0], (total,), (1,), gs[0].storage_offset())
+
+        live = [gs for gs in per if any(g is not None for g in gs)]
+        flats = [flat_of(gs) for gs in live]
+        if live and all(f is not None for f in flats) and len({f.numel() for f in flats}) == 1:
+            # (the rasteriser's backward carves its map gradients out of one allocation, in argument order)
+            total = flats[0] if len(flats) == 1 else sum_buffers(flats)
+            out, o = [], 0
+            for g in live[0]:
+                out.append(total[o:o + g.numel()].view(g.shape))
+                o += g.numel()
+            return (None, *out)
+        out = []
+        for j in range(m):
+            gj = [gs[j] for gs in per if gs[j] is not None]
+            if not gj:
+                out.append(None)
+            elif len(gj) == 1:
+                out.append(gj[0])
+            elif all(ok(g) for g in gj):
+                out.append(sum_buffers(gj))
+            else:
+                acc = gj[0]
+                for g in gj[1:]:
+                    acc = acc + g
+                out.append(acc)
+        return (None, *out)
+
+
+def fan_out(n: int, *tensors):
+    """``n`` tuples of aliases of ``tensors`` for ``n`` consumers (the keyframe renders of a mapping window).  Handing every
+    render its own aliases makes the autograd engine deliver the n gradients of each tensor to ONE node, which adds them in
+    one launch -- all m tensors at once when a consumer returns its gradients back to back in one buffer, as the
+    rasteriser's backward does for (means3D, colours, opacities, scales, rotations) in that order -- instead of n - 1
+    pairwise adds per tensor."""
+    flat = _FanOut.apply(n, *tensors)
+    m = len(tensors)
+    return [flat[k * m:(k + 1) * m] for k in range(n)]
+
+
 def activate(rot_raw: torch.Tensor, scale_raw: torch.Tensor, opacity_raw: torch.Tensor):
     """(normalize(rot_raw), exp(scale_raw) expanded to [P,3], sigmoid(opacity_raw)) in one launch, differentiable."""
     return _Activate.apply(rot_raw, scale_raw, opacity_raw)

@@ -30,7 +30,7 @@ from .renderer import render
 from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
 from . import fused_losses
 from .gaussian_map import GaussianMap
-from .gaussian_optim import activate
+from .gaussian_optim import activate, fan_out
 from .pose_optim import PoseAdam
 from .synthetic import make_scene
 
@@ -94,6 +94,20 @@ def _render(vp, intr, gmap: GaussianMap, bg):
         rot, scales3, opac = activate(gmap._rotation, gmap._scaling, gmap._opacity)
         return render(vp, intr, gmap.get_xyz, rot, scales3, opac, gmap.get_features, bg)
     return render(vp, intr, gmap.get_xyz, gmap.get_rotation, gmap.get_scaling, gmap.get_opacity, gmap.get_features, bg)
+
+
+def _render_lean(vp, intr, xyz, rot, scales3, opac, feat, bg, zero2d):
+    """The rasteriser call of ``render()`` without what an optimisation loop that only needs colour + depth never reads."""
+    view, full, campos = cam.cached_camera_tensors(vp, vp.R, vp.T, intr.projection_matrix)
+    rs = GaussianRasterizationSettings(
+        image_height=int(intr.height), image_width=int(intr.width),
+        tanfovx=math.tan(intr.FoVx * 0.5), tanfovy=math.tan(intr.FoVy * 0.5), bg=bg, scale_modifier=1.0,
+        viewmatrix=view, projmatrix=full, projmatrix_raw=intr.projection_matrix, sh_degree=0, campos=campos,
+        prefiltered=False, debug=False)
+    color, _, depth, _, _ = GaussianRasterizer(rs)(
+        means3D=xyz, means2D=zero2d, opacities=opac, colors_precomp=feat, scales=scales3, rotations=rot,
+        theta=vp.cam_rot_delta, rho=vp.cam_trans_delta)
+    return color, depth
 
 
 class TrackingGraph:
@@ -253,10 +267,20 @@ def run_slam(n_frames=12, intrinsics="fr3_office", tracking_itr_num=100, mapping
     get_loss_mapping, get_loss_tracking = L.get_loss_mapping, L.get_loss_tracking
     bg = torch.zeros(3, device=device)
     kf_streams = [torch.cuda.Stream(device=device) for _ in range(window_size + 1)] if parallel_keyframes else []
+    _z2d = {}
+
+    def zero2d(like):       # the rasteriser's means2D argument when nobody asks for its gradient: one zero tensor per map size
+        key = tuple(like.shape)
+        if key not in _z2d:
+            _z2d.clear()
+            _z2d[key] = torch.zeros(like.shape, device=like.device)
+        return _z2d[key]
     gmap = GaussianMap(device, capturable=graph_mapping)
     window: List[Viewpoint] = []
     per_frame, map_loss = [], []      # (frame, tracking iterations) ; (first, last) mapping loss of every eager window call
-    stats = dict(kf_extend_s=0.0, map_capture_s=0.0, map_replay_s=0.0, map_replay_iters=0, track_capture_s=0.0, track_s=0.0, track_iters=0, tracked=0, map_s=0.0, map_iters=0, keyframes=0, renders=0)
+    warm_stream = torch.cuda.Stream(device=device) if graph_mapping else None
+    graph_pool = torch.cuda.graph_pool_handle() if graph_mapping else None   # one pool for every capture: no fresh hipMalloc per keyframe
+    stats = dict(map_warmup_s=0.0, map_first_replay_s=0.0, kf_extend_s=0.0, map_capture_s=0.0, map_replay_s=0.0, map_replay_iters=0, track_capture_s=0.0, track_s=0.0, track_iters=0, tracked=0, map_s=0.0, map_iters=0, keyframes=0, renders=0)
 
     def sync():
         torch.cuda.synchronize()
@@ -270,23 +294,29 @@ def run_slam(n_frames=12, intrinsics="fr3_office", tracking_itr_num=100, mapping
                             {"params": [vp.exposure_a], "lr": 0.01}, {"params": [vp.exposure_b], "lr": 0.01}]
         kf_opt = torch.optim.Adam(pose_params) if pose_params else None
 
-        def iteration():
+        def iteration(parallel=True):
             if fused_losses_on:          # value + gradients per keyframe, ONE backward through all the renders
                 outs, grads, lgs = [], [], []
-                if parallel_keyframes and len(window) > 1:
+                if gmap.fused_adam and len(window) > 1:
+                    # activations ONCE per iteration; every keyframe renders through its own aliases of the five map tensors,
+                    # so their gradients meet in one node that adds them in one launch (fan_out); no screen-space gradient
+                    # holder and no visibility mask per render (nothing in this loop reads them)
                     main = torch.cuda.current_stream()
-                    rot, scales3, opac = activate(gmap._rotation, gmap._scaling, gmap._opacity)      # once per iteration
-                    xyz, feat = gmap.get_xyz, gmap.get_features
-                    for vp, st in zip(window, kf_streams):
-                        st.wait_stream(main)
-                        with torch.cuda.stream(st):
-                            pkg = render(vp, intr, xyz, rot, scales3, opac, feat, bg)
-                            lg = fused_losses.loss_grads(pkg["render"], pkg["depth"], None, vp, tracking=False, init=init)
-                        outs += [pkg["render"], pkg["depth"]]
+                    rot, scales3, opac = activate(gmap._rotation, gmap._scaling, gmap._opacity)
+                    fans = fan_out(len(window), gmap.get_xyz, gmap.get_features, opac, scales3, rot)
+                    use_streams = parallel and parallel_keyframes
+                    for (xyz_k, feat_k, opac_k, sc_k, rot_k), vp, st in zip(fans, window, kf_streams or [None] * len(window)):
+                        if use_streams:
+                            st.wait_stream(main)
+                        with torch.cuda.stream(st if use_streams else main):
+                            color, depth = _render_lean(vp, intr, xyz_k, rot_k, sc_k, opac_k, feat_k, bg, zero2d(xyz_k))
+                            lg = fused_losses.loss_grads(color, depth, None, vp, tracking=False, init=init)
+                        outs += [color, depth]
                         grads += [lg.d_render, lg.d_depth]
                         lgs.append((vp, lg))
-                    for st in kf_streams[:len(window)]:
-                        main.wait_stream(st)
+                    if use_streams:
+                        for st in kf_streams[:len(window)]:
+                            main.wait_stream(st)
                 else:
                     for vp in window:
                         pkg = _render(vp, intr, gmap, bg)
@@ -313,25 +343,33 @@ def run_slam(n_frames=12, intrinsics="fr3_office", tracking_itr_num=100, mapping
                     pa.zero_grad()
 
         if graph_mapping and fused_pose_on and fused_losses_on and iters >= 8:
-            # two eager iterations on a side stream (Adam state, capacity hints), then capture one and replay
+            # one eager iteration on a side stream (capacity hint for the new map size, lazy state), then capture one and
+            # replay.  The eager one renders the keyframes one after the other: on a stream each it would pull fresh blocks
+            # into six per-stream allocator pools for every new map size (29 ms of hipMalloc per keyframe, measured).
             from . import rasterizer as _r
             sync(); tc0 = time.perf_counter()
-            side = torch.cuda.Stream()
+            side = warm_stream
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                for _ in range(2):
-                    iteration()
+                iteration(parallel=False)
             torch.cuda.current_stream().wait_stream(side)
+            sync(); tw = time.perf_counter()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, pool=graph_pool):
                 iteration()
             sync(); tc1 = time.perf_counter()
+            graph.replay()
+            sync(); tr1 = time.perf_counter()
             for _ in range(iters - 2):
                 graph.replay()
             sync()
+            stats["map_warmup_s"] += tw - tc0
+            stats.setdefault("map_capture_ms_each", []).append((round(1e3 * (tw - tc0), 2), round(1e3 * (tc1 - tw), 2)))
+            stats["map_first_replay_s"] += tr1 - tc1
             stats["map_capture_s"] += tc1 - tc0
-            stats["map_replay_s"] += time.perf_counter() - tc1
+            stats["map_replay_s"] += time.perf_counter() - tr1
             stats["map_replay_iters"] += iters - 2
+            stats["map_iters"] += 0
             stats["map_iters"] += iters
             stats["renders"] += iters * len(window)
             if _r.check_overflow():
@@ -429,6 +467,7 @@ def run_slam(n_frames=12, intrinsics="fr3_office", tracking_itr_num=100, mapping
             sync(); te0 = time.perf_counter()
             gmap.extend_from_frame(vp, intr, downsample=kf_downsample, render_opacity=pkg["opacity"], point_size=point_size)
             sync(); stats["kf_extend_s"] += time.perf_counter() - te0
+            stats.setdefault("kf_extend_ms_each", []).append(round(1e3 * (time.perf_counter() - te0), 2))
             window.append(vp)
             if len(window) > window_size:
                 window.pop(1)

@@ -162,3 +162,52 @@ def test_fused_activations(native_lib, sd):
     sum((r * ww).sum() for r, ww in zip(refs, w)).backward()
     for x, y in zip(a, b):
         assert torch.allclose(x.grad, y.grad, rtol=1e-5, atol=1e-6), (x.grad - y.grad).abs().max()
+
+
+def test_fan_out_sums_the_consumers_gradients_in_one_launch(native_lib):
+    """fan_out(n, *tensors): n consumers of the same tensors; the gradients must equal plain autograd's pairwise sums --
+    through the flat path (each consumer returns its gradients carved from one buffer, as the rasteriser does) and
+    through the per-tensor path (separate buffers, some of them missing)."""
+    from monogs_amd.gaussian_optim import fan_out, sum_buffers
+    g = torch.Generator().manual_seed(3)
+    shapes = [(1000, 3), (1000, 3), (1000, 1), (1000, 3), (1000, 4)]
+    leaves = [torch.randn(s, generator=g).to(DEV).requires_grad_(True) for s in shapes]
+    n = 5
+    w = [[torch.randn(s, generator=g).to(DEV) for s in shapes] for _ in range(n)]
+
+    class Carved(torch.autograd.Function):          # a consumer whose backward returns views of ONE allocation
+        @staticmethod
+        def forward(ctx, k, *ts):
+            ctx.k = k
+            return sum((t * w[k][j]).sum() for j, t in enumerate(ts))
+
+        @staticmethod
+        def backward(ctx, go):
+            flat = torch.cat([(w[ctx.k][j] * go).reshape(-1) for j in range(len(shapes))])
+            out, o = [], 0
+            for s in shapes:
+                m = s[0] * s[1]
+                out.append(flat[o:o + m].view(s))
+                o += m
+            return (None, *out)
+
+    def ref():
+        for t in leaves:
+            t.grad = None
+        sum(sum((t * w[k][j]).sum() for j, t in enumerate(leaves)) for k in range(n)).backward()
+        return [t.grad.clone() for t in leaves]
+    want = ref()
+    for mode in ("flat", "separate"):
+        for t in leaves:
+            t.grad = None
+        fans = fan_out(n, *leaves)
+        if mode == "flat":
+            total = sum(Carved.apply(k, *fans[k]) for k in range(n))
+        else:       # consumer 0 never touches tensor 2: its gradient arrives as None
+            total = sum(sum((t * w[k][j]).sum() for j, t in enumerate(fans[k]) if not (k == 0 and j == 2)) for k in range(n))
+        total.backward()
+        for j, (t, r) in enumerate(zip(leaves, want)):
+            r = r - w[0][2] if (mode == "separate" and j == 2) else r
+            assert torch.allclose(t.grad, r, rtol=1e-5, atol=1e-5), (mode, j)
+    many = [torch.randn(777, generator=g).to(DEV) for _ in range(37)]       # more than 16 sources: groups
+    assert torch.allclose(sum_buffers(many), torch.stack(many).sum(0), rtol=1e-5, atol=1e-5)

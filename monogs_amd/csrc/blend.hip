@@ -249,7 +249,8 @@ __device__ __forceinline__ float reduce10(float a0, float a1, float a2, float a3
     const float b3 = swap32_add(a6, a7), b4 = swap32_add(a8, a9);
     float c0 = swap16_add(b0, b1);     // rows: a0 a2 a1 a3
     float c1 = swap16_add(b2, b3);     // rows: a4 a6 a5 a7
-    float c2 = swap16_add(b4, b4);     // rows: a8 a8 a9 a9
+    float c2 = swz_add<16>(b4);        // rows: a8 a8 a9 a9 (b4 paired with itself: one LDS-crossbar exchange instead of a
+                                       //                    register copy + v_permlane16_swap on the saturated VALU)
     c0 = row_sum_all(c0);
     c1 = row_sum_all(c1);
     c2 = row_sum_all(c2);
@@ -269,7 +270,7 @@ __device__ __forceinline__ int reduce6_slot(int lane) {
 __device__ __forceinline__ float reduce6(float a0, float a1, float a2, float a3, float a4, float a5, int lane) {
     const float b0 = swap32_add(a0, a1), b1 = swap32_add(a2, a3), b2 = swap32_add(a4, a5);
     float c0 = swap16_add(b0, b1);     // rows: a0 a2 a1 a3
-    float c1 = swap16_add(b2, b2);     // rows: a4 a4 a5 a5
+    float c1 = swz_add<16>(b2);        // rows: a4 a4 a5 a5
     c0 = row_sum_all(c0);
     c1 = row_sum_all(c1);
     return (lane & 15) == 15 ? c0 : c1;
@@ -329,6 +330,7 @@ __global__ void __launch_bounds__(256) blend_backward_kernel(BlendArgs a, int nt
     const uint32_t end = range.x + maxc;
 
     const int slot = POSE_ONLY ? reduce6_slot(lane) : reduce10_slot(lane);
+    const uint32_t slot_bytes = slot < 0 ? 0u : (uint32_t)slot * 4u;
 
     uint32_t gid_n = 0;
     float4 box_n = make_float4(0.f, 0.f, -1.f, -1.f), ell_n = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -350,17 +352,19 @@ __global__ void __launch_bounds__(256) blend_backward_kernel(BlendArgs a, int nt
         // pixels whose last contributor is at or behind this step's first instance (1-based position b*64 + 1)
         const unsigned long long alive = __builtin_amdgcn_ballot_w64(last >= (uint32_t)b * WAVE + 1u);
         unsigned long long mask = __builtin_amdgcn_ballot_w64(quadrant_hit(c, el, qx0, qy0, alive));
+        // instance j of this step has the 1-based list position k = b * 64 + j + 1; "k <= last" as ONE compare of the scalar
+        // j with a per-step register (the add of j to a per-lane base was a VALU instruction per survivor)
+        const int rel_last = (int)last - (int)((uint32_t)b * WAVE + 1u);
         while (mask) {
             const int j = 63 - __builtin_clzll(mask);
             mask &= ~(1ull << j);
-            const uint32_t k = (uint32_t)b * WAVE + (uint32_t)j + 1u;     // 1-based position in the tile list
             const uint32_t gid = bcast(gid_l, j);
             const Rec g = fetch(a, gid);
             const float dx = g.px - pxf, dy = g.py - pyf;
             const float power = dx * (g.ca * dx + g.cb * dy) + (g.cc * dy) * dy;   // log2 of the Gaussian falloff
             const float G = __builtin_amdgcn_exp2f(power);
             const float alpha = fminf(0.99f, g.op * G);
-            const bool act = (k <= last) && !(power > 0.f) && !(alpha < 1.0f / 255.0f);
+            const bool act = (j <= rel_last) && !(power > 0.f) && !(alpha < 1.0f / 255.0f);
             if (__builtin_amdgcn_ballot_w64(act) == 0ull) continue;
             // Everything below runs for all 64 lanes; an inactive lane has alpha = 0: it contributes exact zeros
             // (w = 0, h = 0) and its state passes through (T * rcp(1) = T, Bk + 0 * diff = Bk).
@@ -382,7 +386,11 @@ __global__ void __launch_bounds__(256) blend_backward_kernel(BlendArgs a, int nt
             //      10 active lanes covering the Gaussian's 64-byte gradient line
             const float m = POSE_ONLY ? reduce6(s_x, s_y, s_xx, s_xy, s_yy, s_z, lane)
                                       : reduce10(s_x, s_y, s_xx, s_xy, s_yy, s_h, s_r, s_g, s_b, s_z, lane);
-            if (slot >= 0) atomicAdd(grad_acc + (size_t)gid * GRAD_FLOATS + slot, m);
+            // The line address is wave-uniform, the slot a per-lane constant: the atomic takes the line as its SGPR base and
+            // the slot as its 32-bit VGPR offset (written as asm: the compiler folds the slot into a per-lane 64-bit base
+            // and pays a 64-bit VALU add per survivor for the uniform part).  No-return, relaxed: what atomicAdd emitted.
+            float* const line = grad_acc + (size_t)gid * GRAD_FLOATS;
+            if (slot >= 0) asm volatile("global_atomic_add_f32 %0, %1, %2" ::"v"(slot_bytes), "v"(m), "s"(line) : "memory");
         }
     }
 }

@@ -158,7 +158,13 @@ __global__ void __launch_bounds__(256) blend_forward_kernel(BlendArgs a, float* 
             T = cb ? test_T : T;
             last = cb ? (base - range.x) + (uint32_t)j + 1u : last;
             const unsigned long long touched = contrib & __builtin_amdgcn_ballot_w64(test_T > 0.5f);
-            touched_cnt = lane == j ? (int)__popcll(touched) : touched_cnt;   // (v_writelane takes one scalar operand only)
+            // lane j of touched_cnt = popcount: v_writelane_b32 with the lane select in M0 (two SGPR operands exceed the
+            // constant bus; the portable form `lane == j ? cnt : touched_cnt` was v_mov + v_cmp_eq + v_cndmask per survivor).
+            // This kernel has no LDS / GWS / message traffic: nothing else lives in M0.
+            asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0"
+                         : "+v"(touched_cnt)
+                         : "s"((int)__popcll(touched)), "s"(j)
+                         : "m0");
             if (live == 0ull) break;                                       // the whole quadrant is finished
         }
         if (touched_cnt != 0) atomicAdd(n_touched + gid_l, touched_cnt);
@@ -371,7 +377,7 @@ __global__ void __launch_bounds__(256) blend_backward_kernel(BlendArgs a, int nt
             const float a_eff = act ? alpha : 0.f;
             const float inv = __builtin_amdgcn_rcpf(1.f - a_eff);   // v_rcp_f32, not the IEEE divide sequence
             const float Tn = T * inv;
-            const float qq = (g.r * g0 + g.g * g1) + (g.b * g2 + g.z * gd);
+            const float qq = __builtin_fmaf(g.z, gd, __builtin_fmaf(g.b, g2, __builtin_fmaf(g.g, g1, g.r * g0)));   // one chain: 4 VALU, not 5
             const float diff = qq - Bk;
             const float dL_dalpha = diff * Tn + bgT * inv;
             Bk = Bk + a_eff * diff;

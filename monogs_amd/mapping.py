@@ -20,6 +20,7 @@ the owning rank only; ``sync_poses`` all-gathers them before the map is handed o
 """
 from __future__ import annotations
 
+import contextlib
 from typing import Dict, List, Optional, Sequence
 
 import torch
@@ -27,7 +28,7 @@ import torch.distributed as dist
 
 from . import fused_losses, window as W
 from .gaussian_map import GaussianMap
-from .gaussian_optim import activate, add_densification_stats
+from .gaussian_optim import activate, add_densification_stats, fan_out
 from .pose_optim import PoseAdam
 from .renderer import render
 
@@ -69,6 +70,10 @@ class WindowMapper:
         self._bucket = None
         self.map_surgery = True          # False: no densify_and_prune / opacity reset (fixed-size workloads: benchmarks, tests)
         self.keep_reduced_grads = False  # tests: clones of the (all-reduced) Gaussian gradients of the last iteration
+        self.parallel_keyframes = False  # True: render / back-propagate the owned keyframes on a stream each.  Pays inside a
+                                         # captured iteration (slam_harness: 863 -> 1254 it/s); this eager loop is bound by
+                                         # the host issuing its ~300 launches (C4 on one GPU: 5.04 vs 5.14 ms), so it is off
+        self._streams: List = []
         self.last_grads = None
 
     # ---- per-keyframe optimiser state lives on the owning rank ------------------------------------------------------
@@ -77,6 +82,11 @@ class WindowMapper:
         if po is None:
             po = self._pose_opt[id(vp)] = PoseAdam(vp, *self.lrs)
         return po
+
+    def _kf_streams(self, n: int):
+        while len(self._streams) < n:
+            self._streams.append(torch.cuda.Stream(device=self.gmap.device))
+        return self._streams[:n]
 
     def new_keyframe_optimizers(self, viewpoints: Sequence = ()):
         """What the mapper does whenever a keyframe joins the window: ``self.keyframe_optimizers = torch.optim.Adam(...)``
@@ -107,13 +117,36 @@ class WindowMapper:
             P = len(gmap)
             pkgs = {}
             loss = None
-            for k in mine:
-                pkg = render_map(viewpoints[k], self.intr, gmap, self.bg)
-                if pkg is None:
-                    raise ValueError("Render package is None")
-                term = self.loss_fn(pkg["render"], pkg["depth"], viewpoints[k], init=init)
-                loss = term if loss is None else loss + term
+            fans = None
+            if gmap.fused_adam and gmap._rotation.requires_grad and len(mine) > 1:
+                # activations once per iteration, and each render through its own aliases of the five map tensors: their
+                # gradients then meet in ONE node that adds them in one launch (gaussian_optim.fan_out)
+                rot, scales3, opac = activate(gmap._rotation, gmap._scaling, gmap._opacity)
+                fans = fan_out(len(mine), gmap.get_xyz, gmap.get_features, opac, scales3, rot)
+            # the owned keyframes are independent until their losses are added: a stream each (the small latency-bound
+            # kernels of one render overlap the blend kernels of another)
+            streams = self._kf_streams(len(mine)) if (self.parallel_keyframes and len(mine) > 1
+                                                      and torch.device(gmap.device).type == "cuda") else None
+            main = torch.cuda.current_stream() if streams else None
+            terms = []
+            for j, k in enumerate(mine):
+                if streams:
+                    streams[j].wait_stream(main)
+                with (torch.cuda.stream(streams[j]) if streams else contextlib.nullcontext()):
+                    if fans is not None:
+                        xyz_k, feat_k, opac_k, sc_k, rot_k = fans[j]
+                        pkg = render(viewpoints[k], self.intr, xyz_k, rot_k, sc_k, opac_k, feat_k, self.bg)
+                    else:
+                        pkg = render_map(viewpoints[k], self.intr, gmap, self.bg)
+                    if pkg is None:
+                        raise ValueError("Render package is None")
+                    terms.append(self.loss_fn(pkg["render"], pkg["depth"], viewpoints[k], init=init))
                 pkgs[k] = pkg
+            if streams:
+                for st in streams:
+                    main.wait_stream(st)
+            for term in terms:
+                loss = term if loss is None else loss + term
             if loss is not None:
                 loss.backward()
             self.last_loss = loss

@@ -198,8 +198,8 @@ int mgs_dist2_knn(int32_t P, const float* points /* [P,3] */, float* out /* [P] 
  * (mgs_loss_scratch_bytes); mgs_loss_backward turns them into d_render[3,H,W], d_depth[1,H,W] and
  * d_exposure[2] = (dL/da, dL/db; may be NULL), all scaled by the device scalar grad_out (NULL = 1).
  * The opacity image gets no gradient (the rasteriser ignores dL/dopacity).
- * d_exposure may be the two floats at scratch + MGS_LOSS_SCRATCH_DAB, which the forward leaves zeroed: the first
- * backward of a forward can accumulate there without a separate clear (one launch less). */
+ * d_exposure is STORED (scale x the unscaled sums the forward kept in its per-workgroup partials: no atomics, no clear,
+ * bitwise reproducible); it may be the two floats at scratch + MGS_LOSS_SCRATCH_DAB. */
 #define MGS_LOSS_SCRATCH_DAB 10
 #define MGS_LOSS_SCRATCH_LOSS 12
 size_t mgs_loss_scratch_bytes(void);

@@ -21,9 +21,12 @@ namespace mgs {
 constexpr int LS_THREADS = 256;
 constexpr int LS_MAX_BLOCKS = 256;      // forward reduction: two stages, no atomics (64 workgroups were latency-bound: 26 us at VGA)
 // scratch: 16 floats of results followed by LS_MAX_BLOCKS x 8 floats of per-workgroup partial sums
-enum : int { LP_L1_RGB = 6, LP_L1_D = 7, LP_SCALE_RGB = 8, LP_SCALE_D = 9, LP_DAB = 10, LP_LOSS = 12, LP_N = 16, LP_PART = 8 };
-// scratch[LP_DAB .. LP_DAB+1]: left ZERO by the forward; a backward may accumulate d(exposure_a), d(exposure_b) there
-// (d_exposure == scratch + LP_DAB), which saves the launch that clears a separate buffer
+enum : int { LP_L1_RGB = 6, LP_L1_D = 7, LP_SCALE_RGB = 8, LP_SCALE_D = 9, LP_DAB = 10, LP_LOSS = 12, LP_UA = 13, LP_UB = 14, LP_N = 16, LP_PART = 8 };
+// scratch[LP_DAB .. LP_DAB+1]: d(exposure_a), d(exposure_b) of the fused value + gradients call.  The exposure gradients are
+// SUMS over the pixels of terms that differ from the forward's only by a scalar factor (the loss scale): the forward kernel
+// accumulates the unscaled sums U_a = sum exp(a) (s . x), U_b = sum (s0 + s1 + s2) in its per-workgroup partials, and ONE thread
+// of the backward stores scale * U -- no atomics (300 workgroups adding into the same two floats cost 6.6 of the backward's
+// 13.4 us at VGA), no clear, bitwise reproducible.
 
 struct LossArgs {
     const float *render, *depth, *opacity, *gt_rgb, *gt_depth, *exp_a, *exp_b;
@@ -45,7 +48,7 @@ __device__ __forceinline__ float block_sum(float v, float* smem) {
 __device__ __forceinline__ float sgn(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }
 
 // per-pixel terms of the forward sums (shared by the scalar and the 4-pixel paths)
-struct FwdAcc { float s_rgb, c_rgb, s_d, c_d, s_op; };
+struct FwdAcc { float s_rgb, c_rgb, s_d, c_d, s_op, u_a, u_b; };
 __device__ __forceinline__ void fwd_pixel(const LossArgs& a, float ea, float eb, float gd, bool mask, bool gmask, float op,
                                           float r0, float r1, float r2, float g0, float g1, float g2, float d, FwdAcc& acc) {
     bool m_rgb = mask, m_d = gd > 0.f;
@@ -56,8 +59,12 @@ __device__ __forceinline__ void fwd_pixel(const LossArgs& a, float ea, float eb,
         m_d = m_d && opaque;
     }
     if (m_rgb) {
-        acc.s_rgb += fabsf(ea * r0 + eb - g0) + fabsf(ea * r1 + eb - g1) + fabsf(ea * r2 + eb - g2);
+        const float d0 = ea * r0 + eb - g0, d1 = ea * r1 + eb - g1, d2 = ea * r2 + eb - g2;
+        acc.s_rgb += fabsf(d0) + fabsf(d1) + fabsf(d2);
         acc.c_rgb += 3.f;
+        const float s0 = sgn(d0), s1 = sgn(d1), s2 = sgn(d2);
+        acc.u_a += ea * (s0 * r0 + s1 * r1 + s2 * r2);      // d/da of exp(a) x + b, unscaled
+        acc.u_b += s0 + s1 + s2;
     }
     if (m_d) {
         acc.s_d += fabsf(d - gd);
@@ -70,10 +77,10 @@ __device__ __forceinline__ void fwd_pixel(const LossArgs& a, float ea, float eb,
 template <bool VEC4>
 __global__ void __launch_bounds__(LS_THREADS) loss_forward_kernel(LossArgs a, float* __restrict__ part, int zero_dab) {
     __shared__ float smem[4];
-    if (zero_dab && blockIdx.x == 0 && threadIdx.x < 2) part[LP_DAB + threadIdx.x] = 0.f;   // fused mode: no finalize kernel to do it
+    (void)zero_dab;      // (the exposure gradients are stored, not accumulated: nothing to clear)
     const size_t HW = (size_t)a.W * a.H;
     const float ea = a.init ? 1.f : __expf(a.exp_a[0]), eb = a.init ? 0.f : a.exp_b[0];
-    FwdAcc acc = {0.f, 0.f, 0.f, 0.f, 0.f};
+    FwdAcc acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const size_t stride = (size_t)gridDim.x * LS_THREADS;
     if (VEC4) {
         const size_t NQ = HW / 4;
@@ -98,9 +105,10 @@ __global__ void __launch_bounds__(LS_THREADS) loss_forward_kernel(LossArgs a, fl
     }
     const float s_rgb = block_sum(acc.s_rgb, smem), c_rgb = block_sum(acc.c_rgb, smem);
     const float s_d = block_sum(acc.s_d, smem), c_d = block_sum(acc.c_d, smem), s_op = block_sum(acc.s_op, smem);
+    const float u_a = block_sum(acc.u_a, smem), u_b = block_sum(acc.u_b, smem);
     if (threadIdx.x == 0) {
         float* o = part + LP_N + (size_t)blockIdx.x * LP_PART;
-        o[0] = s_rgb; o[1] = c_rgb; o[2] = s_d; o[3] = c_d; o[4] = s_op;
+        o[0] = s_rgb; o[1] = c_rgb; o[2] = s_d; o[3] = c_d; o[4] = s_op; o[5] = u_a; o[6] = u_b;
     }
 }
 
@@ -129,23 +137,24 @@ __device__ __forceinline__ LossScalars loss_scalars(const LossArgs& a, const flo
 }
 
 // one wave: sum the per-workgroup partials in a fixed order (lane l adds blocks l, l+64, ...: bitwise reproducible)
-__device__ __forceinline__ void sum_partials(const float* __restrict__ part, int nblocks, int lane, float v[5]) {
+constexpr int LP_SUMS = 7;
+__device__ __forceinline__ void sum_partials(const float* __restrict__ part, int nblocks, int lane, float v[LP_SUMS]) {
 #pragma unroll
-    for (int k = 0; k < 5; ++k) v[k] = 0.f;
+    for (int k = 0; k < LP_SUMS; ++k) v[k] = 0.f;
     for (int b = lane; b < nblocks; b += WAVE) {
         const float* o = part + LP_N + (size_t)b * LP_PART;
 #pragma unroll
-        for (int k = 0; k < 5; ++k) v[k] += o[k];
+        for (int k = 0; k < LP_SUMS; ++k) v[k] += o[k];
     }
 #pragma unroll
-    for (int k = 0; k < 5; ++k)
+    for (int k = 0; k < LP_SUMS; ++k)
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_xor(v[k], o, 64);
 }
 
 __global__ void loss_finalize_kernel(LossArgs a, int nblocks, float* __restrict__ part, float* __restrict__ loss_out) {
     const int lane = threadIdx.x;
-    float v[5];
+    float v[LP_SUMS];
     sum_partials(part, nblocks, lane, v);
     if (lane == 0) {
         const LossScalars r = loss_scalars(a, v);
@@ -153,8 +162,8 @@ __global__ void loss_finalize_kernel(LossArgs a, int nblocks, float* __restrict_
         part[LP_L1_D] = r.l1_d;
         part[LP_SCALE_RGB] = r.scale_rgb;
         part[LP_SCALE_D] = r.scale_d;
-        part[LP_DAB] = 0.f;
-        part[LP_DAB + 1] = 0.f;
+        part[LP_UA] = v[5];
+        part[LP_UB] = v[6];
         loss_out[0] = r.loss;
     }
 }
@@ -167,14 +176,13 @@ __global__ void __launch_bounds__(LS_THREADS) loss_backward_kernel(LossArgs a, f
                                                                    float* __restrict__ d_render,
                                                                    float* __restrict__ d_depth,
                                                                    float* __restrict__ d_ab) {
-    __shared__ float smem[4];
     __shared__ float s_scale[2];
     const size_t HW = (size_t)a.W * a.H;
     const float go = grad_out ? grad_out[0] : 1.f;
     const float ea = a.init ? 1.f : __expf(a.exp_a[0]), eb = a.init ? 0.f : a.exp_b[0];
     if (fwd_blocks > 0) {
         if (threadIdx.x < WAVE) {
-            float v[5];
+            float v[LP_SUMS];
             sum_partials(part, fwd_blocks, (int)threadIdx.x, v);
             if (threadIdx.x == 0) {
                 const LossScalars r = loss_scalars(a, v);
@@ -182,18 +190,22 @@ __global__ void __launch_bounds__(LS_THREADS) loss_backward_kernel(LossArgs a, f
                 if (blockIdx.x == 0) {
                     part[LP_L1_RGB] = r.l1_rgb; part[LP_L1_D] = r.l1_d; part[LP_SCALE_RGB] = r.scale_rgb;
                     part[LP_SCALE_D] = r.scale_d; part[LP_LOSS] = r.loss;
+                    if (d_ab && !a.init) { d_ab[0] = go * r.scale_rgb * v[5]; d_ab[1] = go * r.scale_rgb * v[6]; }
                 }
             }
         }
         __syncthreads();
     } else if (threadIdx.x == 0) {
         s_scale[0] = part[LP_SCALE_RGB]; s_scale[1] = part[LP_SCALE_D];
+        if (blockIdx.x == 0 && d_ab && !a.init) {
+            d_ab[0] = go * s_scale[0] * part[LP_UA];
+            d_ab[1] = go * s_scale[0] * part[LP_UB];
+        }
     }
     if (fwd_blocks <= 0) __syncthreads();
     const float k_rgb = go * s_scale[0], k_d = go * s_scale[1];
-    float g_a = 0.f, g_b = 0.f;
     const size_t stride = (size_t)gridDim.x * LS_THREADS;
-    // one pixel: returns the three colour gradients and the depth gradient, accumulates the exposure gradients
+    // one pixel: the three colour gradients and the depth gradient (the exposure gradients came out of the forward's sums)
     auto pixel = [&](float gd, bool mask, bool gmask, float op, float x0, float x1, float x2, float t0, float t1, float t2,
                      float d, float& o0, float& o1, float& o2, float& od) {
         bool m_rgb = mask, m_d = gd > 0.f;
@@ -206,8 +218,6 @@ __global__ void __launch_bounds__(LS_THREADS) loss_backward_kernel(LossArgs a, f
         if (m_rgb) {
             const float s0 = sgn(ea * x0 + eb - t0), s1 = sgn(ea * x1 + eb - t1), s2 = sgn(ea * x2 + eb - t2);
             o0 = k_rgb * ea * s0; o1 = k_rgb * ea * s1; o2 = k_rgb * ea * s2;
-            g_a += k_rgb * ea * (s0 * x0 + s1 * x1 + s2 * x2);      // d/da of exp(a) x + b
-            g_b += k_rgb * (s0 + s1 + s2);
         }
         od = m_d ? k_d * sgn(d - gd) : 0.f;
     };
@@ -240,14 +250,6 @@ __global__ void __launch_bounds__(LS_THREADS) loss_backward_kernel(LossArgs a, f
             d_depth[p] = od;
         }
     }
-    if (d_ab && !a.init) {
-        g_a = block_sum(g_a, smem);
-        g_b = block_sum(g_b, smem);
-        if (threadIdx.x == 0) {
-            if (g_a != 0.f) atomicAdd(d_ab, g_a);
-            if (g_b != 0.f) atomicAdd(d_ab + 1, g_b);
-        }
-    }
 }
 
 // four pixels per thread on the vector path
@@ -278,7 +280,7 @@ int launch_loss_forward(const LossArgs& a, float* partials, float* loss_out, hip
 
 int launch_loss_backward(const LossArgs& a, float* partials, const float* grad_out, float* d_render,
                          float* d_depth, float* d_ab, hipStream_t s) {
-    if (d_ab && d_ab != partials + LP_DAB) MGS_HIP(zero_fill(d_ab, 2 * sizeof(float), s));
+    // (d_ab is STORED by one thread of the kernel: no clear)
     if (loss_vec4(a, d_render, d_depth))
         hipLaunchKernelGGL(loss_backward_kernel<true>, dim3(loss_grid(a.W, a.H)), dim3(LS_THREADS), 0, s, a, partials, 0, grad_out,
                            d_render, d_depth, d_ab);

@@ -7,7 +7,7 @@ n=$1; src=$2; shift 2
 base=${src%.hip}
 mkdir -p $ROOT/monogs_amd/lib/variants
 extra=""
-[ "$base" = blend ] && extra="-fno-slp-vectorize"
+[ "$base" = blend ] && extra="-fno-slp-vectorize -Wno-inline-asm"
 [ "$base" = preprocess ] && extra="-ffp-contract=off"
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-gpu-rdc -Wno-unused-function -Wno-unused-variable -DNDEBUG $extra "$@" \
   -c $ROOT/monogs_amd/csrc/$src -o $ROOT/monogs_amd/lib/variants/${base}_$n.o

@@ -75,9 +75,8 @@ __device__ __forceinline__ void fwd_pixel(const LossArgs& a, float ea, float eb,
 // VEC4: every image is read four pixels at a time (16-byte loads; needs H*W % 4 == 0 and 16-byte-aligned images): a
 // thread then has all its loads in flight at once instead of ~11 dependent-latency scalar loads per pixel.
 template <bool VEC4>
-__global__ void __launch_bounds__(LS_THREADS) loss_forward_kernel(LossArgs a, float* __restrict__ part, int zero_dab) {
+__global__ void __launch_bounds__(LS_THREADS) loss_forward_kernel(LossArgs a, float* __restrict__ part) {
     __shared__ float smem[4];
-    (void)zero_dab;      // (the exposure gradients are stored, not accumulated: nothing to clear)
     const size_t HW = (size_t)a.W * a.H;
     const float ea = a.init ? 1.f : __expf(a.exp_a[0]), eb = a.init ? 0.f : a.exp_b[0];
     FwdAcc acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -271,8 +270,8 @@ static int loss_fwd_grid(int W, int H) {
 
 int launch_loss_forward(const LossArgs& a, float* partials, float* loss_out, hipStream_t s) {
     const int nb = loss_fwd_grid(a.W, a.H);
-    if (loss_vec4(a, nullptr, nullptr)) hipLaunchKernelGGL(loss_forward_kernel<true>, dim3(nb), dim3(LS_THREADS), 0, s, a, partials, 0);
-    else hipLaunchKernelGGL(loss_forward_kernel<false>, dim3(nb), dim3(LS_THREADS), 0, s, a, partials, 0);
+    if (loss_vec4(a, nullptr, nullptr)) hipLaunchKernelGGL(loss_forward_kernel<true>, dim3(nb), dim3(LS_THREADS), 0, s, a, partials);
+    else hipLaunchKernelGGL(loss_forward_kernel<false>, dim3(nb), dim3(LS_THREADS), 0, s, a, partials);
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(WAVE), 0, s, a, nb, partials, loss_out);
     MGS_HIP(hipGetLastError());
     return 0;
@@ -296,11 +295,11 @@ int launch_loss_grads(const LossArgs& a, float* partials, float* d_render, float
     const int nb = loss_fwd_grid(a.W, a.H);
     float* d_ab = a.init ? nullptr : partials + LP_DAB;
     if (loss_vec4(a, d_render, d_depth)) {
-        hipLaunchKernelGGL(loss_forward_kernel<true>, dim3(nb), dim3(LS_THREADS), 0, s, a, partials, 1);
+        hipLaunchKernelGGL(loss_forward_kernel<true>, dim3(nb), dim3(LS_THREADS), 0, s, a, partials);
         hipLaunchKernelGGL(loss_backward_kernel<true>, dim3(loss_grid(a.W, a.H)), dim3(LS_THREADS), 0, s, a, partials, nb, nullptr,
                            d_render, d_depth, d_ab);
     } else {
-        hipLaunchKernelGGL(loss_forward_kernel<false>, dim3(nb), dim3(LS_THREADS), 0, s, a, partials, 1);
+        hipLaunchKernelGGL(loss_forward_kernel<false>, dim3(nb), dim3(LS_THREADS), 0, s, a, partials);
         hipLaunchKernelGGL(loss_backward_kernel<false>, dim3(loss_grid(a.W, a.H)), dim3(LS_THREADS), 0, s, a, partials, nb, nullptr,
                            d_render, d_depth, d_ab);
     }

@@ -70,11 +70,10 @@ static inline uint32_t rs_tiles(uint64_t n) {
     return (uint32_t)((n + tile - 1) / tile);
 }
 
-// temp layout: [hist: RS_MAX_PASSES*256 u32][base: RS_MAX_PASSES*256 u32][tickets: RS_MAX_PASSES u32]
-//              [error: RS_MAX_PASSES u32][pad][status: passes * tiles * 256 u64]
+// temp layout: [hist: RS_MAX_PASSES*256 u32][tickets: RS_MAX_PASSES u32][error: RS_MAX_PASSES u32][pad]
+//              [status: passes * tiles * 256 u64]
 struct RsTemp {
     uint32_t* hist;
-    uint32_t* base;
     uint32_t* tickets;
     uint32_t* error;
     uint64_t* status;
@@ -84,8 +83,7 @@ static RsTemp rs_carve(void* temp, uint64_t n, int bits) {
     char* p = (char*)align_up((size_t)temp, 256);
     RsTemp t;
     t.hist = (uint32_t*)p;
-    t.base = t.hist + RS_MAX_PASSES * RS_RADIX;
-    t.tickets = t.base + RS_MAX_PASSES * RS_RADIX;
+    t.tickets = t.hist + RS_MAX_PASSES * RS_RADIX;
     t.error = t.tickets + RS_MAX_PASSES;      // one word per pass
     char* q = (char*)align_up((size_t)(t.error + RS_MAX_PASSES), 256);
     t.status = (uint64_t*)q;
@@ -100,7 +98,6 @@ size_t radix_temp_bytes(uint64_t n, int bits) {
 }
 
 // ------------------------------------------------------------------------------------------------
-struct RsShifts { int npasses; };
 
 // Digit counts of every pass in one read of the keys.  Each wave keeps a private copy of the
 // histograms in LDS (4x fewer same-address LDS atomics; the tile-id digits are low-entropy).

@@ -132,8 +132,8 @@ int mgs_forward_render(const mgs_camera* cam, int32_t P, uint64_t num_rendered,
 /* Test knob: the bound of the look-back spin (device-wide, all later sorts); 0xFFFFFFFF restores the default. */
 int mgs_debug_set_radix_spin_limit(uint32_t limit);
 /* Test knobs that force an algorithm path whatever the problem size (process-wide; -1 restores the default):
- * "radix_scanned" (0 = one-sweep look-back, 1 = pre-scanned offsets), "knn_grid_min" (Morton-box kNN from this many
- * points).  Nothing on the launch path consults the environment. */
+ * "radix_scanned" (0 = one-sweep look-back, 1 = pre-scanned offsets), "scan_small" (0 = the two-launch scan at every size),
+ * "knn_grid_min" (Morton-box kNN from this many points).  Nothing on the launch path consults the environment. */
 int mgs_debug_set_option(const char* name, int64_t value);
 
 /* Forward, stage 2 without a host-side instance count ("capacity mode"): call mgs_forward_preprocess with

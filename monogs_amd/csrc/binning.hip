@@ -129,7 +129,8 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_small_kernel(const uint2* _
     }
     if (threadIdx.x == 0 && (int)blockIdx.x == nb - 1) block_sums[nb] = s_prefix + total;
 }
-bool scan_is_small(int P) { return scan_nblocks(P) <= SCAN_SMALL_MAX_BLOCKS; }
+int g_opt_scan_small = -1;          // mgs_debug_set_option("scan_small", -1 | 0 | 1): 0 = always the two-launch scan
+bool scan_is_small(int P) { return g_opt_scan_small != 0 && scan_nblocks(P) <= SCAN_SMALL_MAX_BLOCKS; }
 
 // (There is no third "add the block offset" pass: the only consumer of the offsets, duplicate_kernel, adds
 //  block_sums[i / SCAN_ITEMS] itself -- one launch and a 16-byte-per-Gaussian read-modify-write less.)

@@ -20,12 +20,11 @@ from __future__ import annotations
 
 import math
 import time
-from typing import List, Optional
+from typing import List
 
 import torch
 
 from . import camera as cam
-from .knn import distCUDA2
 from .renderer import render
 from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
 from . import fused_losses

@@ -306,6 +306,38 @@ def test_radix_lookback_timeout_is_reported_in_every_mode(native_lib):
     assert torch.equal(out[0], ref[0])
 
 
+def test_scan_paths_agree(native_lib):
+    """The single-launch scan of SLAM-sized maps (block totals all-gathered through status words) and the two-launch scan of
+    large ones give the same offsets: tables and image bit for bit, in the exact and in the capacity mode."""
+    from monogs_amd import _lib
+    from monogs_amd import rasterizer as R
+    from monogs_amd.debug import forward_tables
+    from monogs_amd.rasterizer import GaussianRasterizer
+    lib = _lib.load()
+    sc = make_scene(70000, "fr3_office", seed=9)          # 35 scan blocks
+    st = _hip_st(sc)
+    dev = lambda t: t.to(DEV)  # noqa: E731
+    args = dict(colors_precomp=dev(sc.colors), scales=dev(sc.scales), rotations=dev(sc.rotations))
+    one = forward_tables(st, dev(sc.means3D), dev(sc.opacities), **args)
+    full = dict(means3D=dev(sc.means3D), means2D=torch.zeros(70000, 3, device=DEV), opacities=dev(sc.opacities), **args)
+    R.set_sync_free(True)
+    try:
+        with torch.no_grad():
+            cap_one = GaussianRasterizer(st)(**full)
+        lib.mgs_debug_set_option(b"scan_small", 0)
+        two = forward_tables(st, dev(sc.means3D), dev(sc.opacities), **args)
+        with torch.no_grad():
+            cap_two = GaussianRasterizer(st)(**full)
+        assert not R.check_overflow()
+    finally:
+        lib.mgs_debug_set_option(b"scan_small", -1)
+        R.set_sync_free(False)
+    assert one["num_rendered"] == two["num_rendered"] > 0
+    for k in ("ranges", "point_list", "tile_sorted", "color", "n_contrib", "n_touched"):
+        assert torch.equal(one[k], two[k]), k
+    assert torch.equal(cap_one[0], cap_two[0]) and torch.equal(cap_one[0], one["color"])
+
+
 def test_tile_sort_timeout_raises_its_own_status_bit_and_blends_nothing(native_lib):
     """A look-back timeout in the TILE sort (the depth sort healthy): the status word carries MGS_STATUS_TILE_SORT_TIMEOUT,
     the tile ranges stay empty and nothing is blended -- no instance index is ever read from the half-written list."""

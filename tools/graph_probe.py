@@ -7,7 +7,7 @@ import torch
 
 from monogs_amd import rasterizer as _r
 from monogs_amd.renderer import render
-from monogs_amd.slam_harness import Intrinsics, Viewpoint, make_sequence, GaussianMap
+from monogs_amd.slam_harness import make_sequence
 from monogs_amd import fused_losses
 from monogs_amd.pose_optim import PoseAdam
 

@@ -29,7 +29,10 @@ def forward_tables(rs, means3D, opacities, colors_precomp=None, shs=None, scales
     rotations, cov3D_precomp = c(rotations, "rotations"), c(cov3D_precomp, "cov3D")
     with _device_guard(dev):
         keep = []
-        cam = _camera(rs, 0 if shs is None else shs.shape[1], keep)
+        scale_dim = int(scales.shape[1]) if scales is not None else 3       # [P,1]: isotropic, expanded inside the kernels
+        if scale_dim not in (1, 3):
+            raise Exception("scales must be [P,3] (or [P,1] for an isotropic map)")
+        cam = _camera(rs, 0 if shs is None else shs.shape[1], keep, scale_dim)
         u8 = dict(dtype=torch.uint8, device=dev)
         geom = torch.zeros(lib.mgs_geometry_bytes(P), **u8)
         img = torch.zeros(lib.mgs_image_bytes(W, H), **u8)

@@ -11,7 +11,11 @@ restatement of the published algorithm, pinned by
   * the reference helpers that *do* import here (pose retraction, camera matrices, SH
     evaluation; see tests/golden/make_golden.py and tests/test_golden.py),
   * float64 ``torch.autograd.gradcheck`` and central finite differences of the pose Jacobian,
-  * known-answer cases (tests/test_oracle_kat.py).
+  * known-answer cases (tests/test_oracle_kat.py),
+  * the reference's OpenGL viewer shaders, the only splatting code it holds: covariance, EWA projection (1.3 tan(fov)
+    clamp, +0.3 low-pass), conic and the per-fragment alpha rule restated from
+    /root/reference/viewer/gl_render/shaders/gau_vert.glsl:60-107,149-154 and gau_frag.glsl:20-25
+    (tests/test_reference_shader.py).
 """
 from .gs_oracle import (  # noqa: F401
     OracleSettings,

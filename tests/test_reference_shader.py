@@ -166,3 +166,26 @@ def test_sh_constants_match_the_viewer_shader():
                                      0.5462742152960396]
     assert list(gs_oracle.SH_C3) == [-0.5900435899266435, 2.890611442640554, -0.4570457994644658, 0.3731763325901154,
                                      -0.4570457994644658, 1.445305721320277, -0.5900435899266435]
+
+
+def test_cov3d_matches_the_reference_python_covariance():
+    """`GaussianModel.build_covariance_from_scaling_rotation` (/root/reference/gaussian_splatting/scene/gaussian_model.py:76-82)
+    with `build_scaling_rotation` / `build_rotation` / `strip_symmetric` (gaussian_splatting/utils/general_utils.py:97-148),
+    restated in numpy (they allocate on "cuda" and cannot run in the build container): L = R diag(mod * s), Sigma = L L^T, six
+    upper-triangular entries in the order (xx, xy, xz, yy, yz, zz).  The rasteriser receives unit quaternions (the rotation
+    activation is `normalize`, gaussian_model.py:68), for which `build_rotation`'s own normalisation is the identity."""
+    sc, st = _scene(300, seed=34)
+    q = sc.rotations.double().numpy()
+    q = q / np.sqrt((q * q).sum(1, keepdims=True))                                   # build_rotation:114-118
+    r, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    R = np.zeros((q.shape[0], 3, 3))
+    R[:, 0, 0] = 1 - 2 * (y * y + z * z); R[:, 0, 1] = 2 * (x * y - r * z); R[:, 0, 2] = 2 * (x * z + r * y)   # noqa: E702
+    R[:, 1, 0] = 2 * (x * y + r * z); R[:, 1, 1] = 1 - 2 * (x * x + z * z); R[:, 1, 2] = 2 * (y * z - r * x)   # noqa: E702
+    R[:, 2, 0] = 2 * (x * z - r * y); R[:, 2, 1] = 2 * (y * z + r * x); R[:, 2, 2] = 1 - 2 * (x * x + y * y)   # noqa: E702
+    s = sc.scales.double().numpy() * 1.7
+    s = s if s.shape[1] == 3 else np.repeat(s, 3, axis=1)
+    L = R @ np.stack([np.diag(v) for v in s])                                        # build_scaling_rotation:139-148
+    cov = L @ L.transpose(0, 2, 1)
+    want = np.stack([cov[:, 0, 0], cov[:, 0, 1], cov[:, 0, 2], cov[:, 1, 1], cov[:, 1, 2], cov[:, 2, 2]], 1)   # strip_lowerdiag
+    got = gs_oracle.cov3d_from_scale_rot(torch.from_numpy(s / 1.7), torch.from_numpy(q), torch.tensor(1.7, dtype=torch.float64)).numpy()
+    assert np.allclose(got, want, rtol=1e-12, atol=1e-14)

@@ -133,6 +133,7 @@ int mgs_forward_render(const mgs_camera* cam, int32_t P, uint64_t num_rendered,
 int mgs_debug_set_radix_spin_limit(uint32_t limit);
 /* Test knobs that force an algorithm path whatever the problem size (process-wide; -1 restores the default):
  * "radix_scanned" (0 = one-sweep look-back, 1 = pre-scanned offsets), "scan_small" (0 = the two-launch scan at every size),
+ * "dup_slot_major" (0 / 1 = the duplicate kernel's emission balanced by Gaussians / by output slots at every size),
  * "knn_grid_min" (Morton-box kNN from this many points).  Nothing on the launch path consults the environment. */
 int mgs_debug_set_option(const char* name, int64_t value);
 

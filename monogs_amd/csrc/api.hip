@@ -320,6 +320,7 @@ int mgs_debug_set_radix_spin_limit(uint32_t limit) { return set_radix_spin_limit
 
 int mgs_debug_set_option(const char* name, int64_t value) {
     if (name && !strcmp(name, "radix_scanned")) { g_opt_radix_scanned = (int)value; return 0; }
+    if (name && !strcmp(name, "dup_slot_major")) { g_opt_dup_slot_major = (int)value; return 0; }
     if (name && !strcmp(name, "scan_small")) { g_opt_scan_small = (int)value; return 0; }
     if (name && !strcmp(name, "knn_grid_min")) { g_opt_knn_grid_min = value > 0x7FFFFFFF ? 0x7FFFFFFF : (int)value; return 0; }
     set_error("mgs_debug_set_option: unknown option");

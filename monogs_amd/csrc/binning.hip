@@ -167,13 +167,12 @@ __global__ void __launch_bounds__(256) duplicate_kernel(int P, const uint2* __re
                                                         int ntiles, uint32_t* __restrict__ zero_ptr, size_t zero_words,
                                                         uint32_t* __restrict__ count, uint32_t* __restrict__ overflow,
                                                         const uint32_t* __restrict__ depth_err, int offsets_global,
-                                                        uint32_t* __restrict__ hist /* [4][256] or NULL */, int hist_passes) {
+                                                        uint32_t* __restrict__ hist /* [4][256] or NULL */, int hist_passes,
+                                                        int n_threads /* of this launch */, int slot_major) {
     const int i = blockIdx.x * 256 + threadIdx.x;          // (launched with 256 threads; blockDim would be a packet fetch)
     const int lane = threadIdx.x & 63;
-    {   // scratch of the tile sort that follows (was its own launch); the launch has max(P, ntiles) threads, rounded up
-        const int n_thr = P > ntiles ? P : ntiles;
-        grid_zero(zero_ptr, zero_words, (size_t)((n_thr + 255) / 256) * 256, 256);
-    }
+    // scratch of the tile sort that follows (was its own launch)
+    grid_zero(zero_ptr, zero_words, (size_t)n_threads, 256);
     // a depth sort whose look-back timed out left perm / rect_sorted / offsets partly unwritten: emit nothing (the live
     // count is published as 0, so the tile sort, the ranges and the blend kernels have nothing to do either)
     const bool depth_bad = depth_err && radix_failed(depth_err) != 0u;
@@ -214,6 +213,97 @@ __global__ void __launch_bounds__(256) duplicate_kernel(int P, const uint2* __re
         __syncthreads();
     }
     const int wv = threadIdx.x >> 6;
+    if (slot_major) {
+        // ---- emission balanced by OUTPUT SLOTS.  Gaussian-major (below), a wave owns the slots of its 64 Gaussians: in depth
+        // order the near ones come first and cover hundreds of tiles each, so the first waves of the launch walk tens of
+        // thousands of slots while most walk a few dozen (102 k Gaussians at 1200x680: 81 us for 1.3 M instances, against
+        // 19 us for 5.3 M at C5 where every splat is small).  Here every wave of the launch owns an equal share [s0, s1) of
+        // the slots, finds the Gaussian that owns s0 by a 64-way search of the scanned offsets (3 dependent probes at
+        // 100 k Gaussians) and walks the Gaussians from there, 64 at a time, with the same owner-marking as below.
+        const uint32_t R_all = (P > 0 && !depth_bad) ? block_sums[scan_nblocks_dev(P)] : 0u;
+        const uint32_t R_emit = min(R_all, r_cap);
+        const uint32_t n_waves = (uint32_t)n_threads / WAVE;
+        const uint32_t CH = (((R_emit + n_waves - 1u) / n_waves) + 63u) & ~63u;
+        const uint32_t wave_id = (uint32_t)blockIdx.x * 4u + (uint32_t)wv;
+        const uint32_t s0 = min(R_emit, wave_id * CH), s1 = min(R_emit, s0 + CH);
+        auto incl = [&](uint32_t k) { return offsets[k] + (offsets_global ? 0u : block_sums[k / SCAN_ITEMS]); };
+        uint32_t g = 0;
+        if (s0 < s1) {      // smallest g with incl(g) > s0: it exists because incl(P - 1) = R_all > s0
+            uint32_t lo = 0, hi = (uint32_t)P;
+            while (hi - lo > 1u) {
+                const uint32_t span = hi - lo, step = (span + 63u) / 64u;
+                const uint32_t probe = lo + min(((uint32_t)lane + 1u) * step, span) - 1u;
+                const unsigned long long above = __builtin_amdgcn_ballot_w64(incl(probe) > s0);      // monotone in the lane
+                const int k = __builtin_ctzll(above);                                                // (the last probe is hi - 1: set)
+                const uint32_t pk = lo + min(((uint32_t)k + 1u) * step, span) - 1u;
+                const uint32_t pk1 = k == 0 ? lo : lo + min((uint32_t)k * step, span);               // one past probe k - 1
+                lo = pk1; hi = pk + 1u;
+            }
+            g = lo;
+        }
+        uint32_t sl = s0;
+        while (sl < s1 && g < (uint32_t)P) {                                   // wave-uniform
+            const uint32_t gi = g + (uint32_t)lane;
+            const bool valid = gi < (uint32_t)P;
+            uint32_t inc = 0, ntg = 0, idg = 0;
+            int gx0 = 0, gy0 = 0, gw = 1;
+            if (valid) {
+                inc = incl(gi);
+                const uint2 r = rects[gi];
+                gw = (int)(r.y & 0xFFFFu);
+                ntg = (uint32_t)(gw * (int)(r.y >> 16));
+                gx0 = (int)(r.x & 0xFFFFu); gy0 = (int)(r.x >> 16);
+                idg = perm[gi];
+            }
+            const uint32_t exc = inc - ntg;                                    // first slot of the Gaussian
+            uint32_t Eg = valid ? inc : 0u;                                    // end of the group's slots = the largest inclusive sum
+#pragma unroll
+            for (int o2 = 32; o2 > 0; o2 >>= 1) Eg = max(Eg, (uint32_t)__shfl_xor((int)Eg, o2, 64));
+            __builtin_amdgcn_wave_barrier();
+            s_idx[wv][lane] = idg; s_off[wv][lane] = exc; s_x0[wv][lane] = gx0; s_y0[wv][lane] = gy0; s_w[wv][lane] = max(gw, 1);
+            const uint32_t e = min(s1, Eg);
+            const uint32_t cb0 = sl & ~63u;
+            const unsigned long long before = __builtin_amdgcn_ballot_w64(ntg != 0u && exc < cb0);
+            uint32_t carry = before ? 64u - (uint32_t)__builtin_clzll(before) : 0u;      // owner (lane + 1) of the slot before the chunk
+            for (uint32_t cb = cb0; cb < e; cb += WAVE) {
+                __builtin_amdgcn_wave_barrier();
+                s_own[wv][lane] = 0u;
+                __builtin_amdgcn_wave_barrier();
+                if (ntg != 0u && exc >= cb && exc < cb + WAVE) s_own[wv][exc - cb] = (uint32_t)lane + 1u;
+                __builtin_amdgcn_wave_barrier();
+                uint32_t m = s_own[wv][lane];
+#define MGS_DPP_MAX(ctrl, row_mask) m = max(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, ctrl, row_mask, 0xf, false))
+                MGS_DPP_MAX(0x111, 0xf); MGS_DPP_MAX(0x112, 0xf); MGS_DPP_MAX(0x114, 0xf); MGS_DPP_MAX(0x118, 0xf);
+                MGS_DPP_MAX(0x142, 0xa); MGS_DPP_MAX(0x143, 0xc);
+#undef MGS_DPP_MAX
+                const uint32_t owner = max(m, carry);
+                carry = (uint32_t)__builtin_amdgcn_readlane((int)owner, 63);
+                const uint32_t o = cb + lane;
+                if (owner != 0u && o >= sl && o < e) {                        // (e <= R_emit <= r_cap: never past the buffers)
+                    const uint32_t L = owner - 1u;
+                    const uint32_t t = o - s_off[wv][L];
+                    const uint32_t w = (uint32_t)s_w[wv][L];
+                    const uint32_t yy = t / w, xx = t - yy * w;
+                    const uint32_t key = (uint32_t)((s_y0[wv][L] + (int)yy) * gx + s_x0[wv][L] + (int)xx);
+                    keys[o] = key;
+                    vals[o] = s_idx[wv][L];
+                    if (hist) {
+                        atomicAdd(&s_hist[0][key & 0xFFu], 1u);
+                        if (hist_passes > 1) atomicAdd(&s_hist[1][(key >> 8) & 0xFFu], 1u);
+                    }
+                }
+            }
+            sl = max(sl, e);
+            if (Eg <= sl) g += WAVE;                                           // the group is used up
+        }
+        if (hist) {
+            __syncthreads();
+            const uint32_t c0 = s_hist[0][threadIdx.x], c1 = s_hist[1][threadIdx.x];
+            if (c0) atomicAdd(hist + threadIdx.x, c0);
+            if (c1) atomicAdd(hist + 256 + threadIdx.x, c1);
+        }
+        return;
+    }
     s_idx[wv][lane] = idx; s_off[wv][lane] = off; s_x0[wv][lane] = x0; s_y0[wv][lane] = y0; s_w[wv][lane] = max(x1 - x0, 1);
     const unsigned long long live = __builtin_amdgcn_ballot_w64(nt != 0);
     if (live == 0ull && !hist) return;                                      // wave-uniform
@@ -264,22 +354,36 @@ __global__ void __launch_bounds__(256) duplicate_kernel(int P, const uint2* __re
     }
 }
 
+constexpr uint64_t DUP_SLOT_MAJOR_MIN = 768ull * 1024;      // instances (capacity in capacity mode)
+int g_opt_dup_slot_major = -1;      // mgs_debug_set_option("dup_slot_major", -1 | 0 | 1): -1 = by size
+
 int launch_duplicate(const mgs_camera& cam, int P, const GeometryState& g, const BinningState& b, uint64_t r_cap,
                      int32_t* n_touched, const ImageState& img, uint64_t sort_n, int sort_bits, uint32_t* count,
                      uint32_t* overflow, hipStream_t s) {
     const uint32_t* depth_err = P > 0 ? radix_error_flag(g.sort_temp, (uint64_t)P, 32) : nullptr;
     const int ntiles = tiles_x(cam.image_width) * tiles_y(cam.image_height);
-    const int n = P > ntiles ? P : ntiles;
+    int n = P > ntiles ? P : ntiles;
     if (n == 0) return 0;
+    // Many instances AND many instances per Gaussian (big splats: the near ones cover hundreds of tiles): emission balanced by
+    // output slots (see the kernel), with enough waves for ~512 slots each.  Otherwise the Gaussian-major walk: no search, fewer
+    // loads per slot (C5, 2.6 instances per Gaussian: 22 us against 31 us slot-major; 102 k Gaussians at 1200x680, 13 per
+    // Gaussian: 81 us against 8.6 us; 39 k at VGA, 415 k instances: 7.5 against 8.8 us).
+    const bool slot_major = P > 0 && g_opt_dup_slot_major != 0 &&
+                            (g_opt_dup_slot_major > 0 || (sort_n >= DUP_SLOT_MAJOR_MIN && sort_n >= 6ull * (uint64_t)P));
+    if (slot_major) {
+        const uint64_t want = sort_n / 8;
+        if (want > (uint64_t)n) n = (int)(want > 0x3FFFFFFFull ? 0x3FFFFFFFull : want);
+    }
+    const int n_threads = (n + 255) / 256 * 256;
     uint32_t* zero_ptr = nullptr;
     size_t zero_words = 0;
     if (sort_n > 0) radix_zero_region(b.sort_temp, sort_n, sort_bits, &zero_ptr, &zero_words);
     const bool count_digits = P > 0 && sort_bits <= 16 && radix_wants_hist(sort_n);
-    hipLaunchKernelGGL(duplicate_kernel, dim3((n + 255) / 256), dim3(256), 0, s, P, g.rect_sorted, g.perm, g.point_offsets,
+    hipLaunchKernelGGL(duplicate_kernel, dim3(n_threads / 256), dim3(256), 0, s, P, g.rect_sorted, g.perm, g.point_offsets,
                        g.scan_blocks, b.keys_a, b.vals_a, tiles_x(cam.image_width), tiles_y(cam.image_height),
                        (uint32_t)(r_cap > 0xFFFFFFFFull ? 0xFFFFFFFFull : r_cap), n_touched, img.ranges, ntiles, zero_ptr,
                        zero_words, count, overflow, depth_err, (P > 0 && scan_is_small(P)) ? 1 : 0,
-                       count_digits ? g.tile_hist : nullptr, (sort_bits + 7) / 8);
+                       count_digits ? g.tile_hist : nullptr, (sort_bits + 7) / 8, n_threads, slot_major ? 1 : 0);
     MGS_HIP(hipGetLastError());
     return 0;
 }

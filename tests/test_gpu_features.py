@@ -338,6 +338,41 @@ def test_scan_paths_agree(native_lib):
     assert torch.equal(cap_one[0], cap_two[0]) and torch.equal(cap_one[0], one["color"])
 
 
+@pytest.mark.parametrize("n,intr", [(3000, "fr3_office"), (70000, "fr3_office"), (40000, "replica")])
+def test_duplicate_emission_paths_agree(native_lib, n, intr):
+    """duplicate_kernel emits the (tile, Gaussian) instances either Gaussian-major (a wave owns the slots of its 64
+    Gaussians) or slot-major (every wave owns an equal share of the output slots and searches its first Gaussian): same
+    keys, same values, hence the same tables and image, in the exact and in the capacity mode."""
+    from monogs_amd import _lib
+    from monogs_amd import rasterizer as R
+    from monogs_amd.debug import forward_tables
+    from monogs_amd.rasterizer import GaussianRasterizer
+    lib = _lib.load()
+    sc = make_scene(n, intr, seed=13)
+    st = _hip_st(sc)
+    dev = lambda t: t.to(DEV)  # noqa: E731
+    args = dict(colors_precomp=dev(sc.colors), scales=dev(sc.scales), rotations=dev(sc.rotations))
+    full = dict(means3D=dev(sc.means3D), means2D=torch.zeros(n, 3, device=DEV), opacities=dev(sc.opacities), **args)
+    out = {}
+    try:
+        for mode in (0, 1):
+            lib.mgs_debug_set_option(b"dup_slot_major", mode)
+            out[mode] = forward_tables(st, dev(sc.means3D), dev(sc.opacities), **args)
+            R.set_sync_free(True)
+            with torch.no_grad():
+                GaussianRasterizer(st)(**full)                                  # (records the capacity hint)
+                out[mode]["cap"] = GaussianRasterizer(st)(**full)[0]
+            assert not R.check_overflow()
+            R.set_sync_free(False)
+    finally:
+        lib.mgs_debug_set_option(b"dup_slot_major", -1)
+        R.set_sync_free(False)
+    assert out[0]["num_rendered"] == out[1]["num_rendered"] > 0
+    for k in ("ranges", "point_list", "tile_sorted", "color", "n_contrib", "n_touched"):
+        assert torch.equal(out[0][k], out[1][k]), k
+    assert torch.equal(out[0]["cap"], out[1]["cap"]) and torch.equal(out[0]["cap"], out[0]["color"])
+
+
 def test_tile_sort_timeout_raises_its_own_status_bit_and_blends_nothing(native_lib):
     """A look-back timeout in the TILE sort (the depth sort healthy): the status word carries MGS_STATUS_TILE_SORT_TIMEOUT,
     the tile ranges stay empty and nothing is blended -- no instance index is ever read from the half-written list."""

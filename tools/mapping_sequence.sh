@@ -6,6 +6,6 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pm_$tag
-rocprofv3 --kernel-trace --output-format csv -d /tmp/pm_$tag -o s -- python3 $R/tools/slam_bench.py --config tum --graph --frames $frames > $O/${tag}_slam_trace_run.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d /tmp/pm_$tag -o s -- python3 $R/tools/slam_bench.py --config ${CFG:-tum} --graph --frames $frames > $O/${tag}_slam_trace_run.log 2>&1
 python3 $R/tools/kernel_sequence.py $(find /tmp/pm_$tag -name '*kernel_trace.csv' | head -1) adam_kernel -1 > $O/${tag}_mapping_replay_kernel_sequence.txt 2>&1
 tail -3 $O/${tag}_mapping_replay_kernel_sequence.txt

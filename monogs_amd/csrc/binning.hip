@@ -289,7 +289,13 @@ __global__ void __launch_bounds__(256) duplicate_kernel(int P, const uint2* __re
                     vals[o] = s_idx[wv][L];
                     if (hist) {
                         atomicAdd(&s_hist[0][key & 0xFFu], 1u);
-                        if (hist_passes > 1) atomicAdd(&s_hist[1][(key >> 8) & 0xFFu], 1u);
+                        if (hist_passes > 1) {      // (few values: the lanes that share the first active lane's digit add once)
+                            const uint32_t d1 = (key >> 8) & 0xFFu;
+                            const uint32_t lead = (uint32_t)__builtin_amdgcn_readfirstlane((int)d1);
+                            const unsigned long long same = __builtin_amdgcn_ballot_w64(d1 == lead);
+                            if (d1 != lead) atomicAdd(&s_hist[1][d1], 1u);
+                            else if (lane == (int)__builtin_ctzll(same)) atomicAdd(&s_hist[1][lead], (uint32_t)__popcll(same));
+                        }
                     }
                 }
             }

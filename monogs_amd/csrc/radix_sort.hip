@@ -6,7 +6,7 @@
 //
 // Two paths, bit-identical results, chosen by size (rs_scanned()):
 //
-// "One sweep" (<= 1 M pairs: every sort of a SLAM-sized map; fewest launches):
+// "One sweep" (<= 640 k pairs: every sort of a SLAM-sized map; fewest launches):
 //   * ONE histogram kernel reads the keys once and counts every digit of every pass (each pass kernel
 //     scans its 256 counts into exclusive global bases itself);
 //   * per pass ONE kernel.  A workgroup (256 threads = 4 waves) takes a tile of 1024-4096 pairs, ranks
@@ -14,7 +14,7 @@
 //     digit counts, obtains the sum of the counts of all EARLIER tiles by decoupled look-back, lays
 //     the tile out digit-by-digit in LDS and writes each digit's run to its final place (coalesced
 //     runs instead of a 256-way scatter).
-// "Pre-scanned offsets" (> 1 M pairs): per pass rs_tile_hist_kernel (digit counts of every tile),
+// "Pre-scanned offsets" (> 640 k pairs): per pass rs_tile_hist_kernel (digit counts of every tile),
 //   rs_row_scan_kernel (exclusive scan along the tiles of each digit + digit totals) and the same
 //   ranking / scatter kernel reading its offsets from that table -- no waiting between workgroups.  With
 //   hundreds of co-resident tiles the look-back's status traffic and round trips dominated the pass.
@@ -40,8 +40,11 @@ constexpr int RS_ITEMS_SMALL = 4;                  // small sorts are latency-bo
 // 400 k: 108 us (4); 2 M: 158 us (16) / 208 us (8) / 152 us (32).  Pre-scanned path, round 2 (C5): 16 -> 8 items leaves the
 // depth sort at 0.136 ms and takes the tile sort from 0.094 to 0.105 ms; 32 items: 0.168 / 0.116 ms.  A few hundred tiles is the sweet spot between the per-tile
 // ranking latency and the length of the look-back chain.
+// Above this many pairs the pre-scanned path takes over.  Round 2: 1 M keys (depth sort): one sweep 0.134 ms, pre-scanned
+// 0.101 ms; 500 k: 0.087 vs 0.092 ms; 300 k: 0.075 vs 0.088 ms -- the crossover sits between 512 k and 1 M.
+constexpr uint64_t RS_ONE_SWEEP_MAX = 640ull * 1024;
 static inline int rs_items(uint64_t n) {
-    return n <= 192ull * 1024 ? RS_ITEMS_SMALL : (n <= 1024ull * 1024 ? RS_ITEMS_MID : RS_ITEMS);
+    return n <= 192ull * 1024 ? RS_ITEMS_SMALL : (n <= RS_ONE_SWEEP_MAX ? RS_ITEMS_MID : RS_ITEMS);
 }
 constexpr int RS_RADIX = 256;
 constexpr int RS_MAX_PASSES = 4;
@@ -62,7 +65,7 @@ constexpr int RS_WINDOW = 16;
 int g_opt_radix_scanned = -1;       // mgs_debug_set_option("radix_scanned", -1 | 0 | 1): -1 = by size
 static inline bool rs_scanned(uint64_t n) {
     if (g_opt_radix_scanned >= 0) return g_opt_radix_scanned == 1 && rs_items(n) == RS_ITEMS;
-    return rs_items(n) == RS_ITEMS;          // > 1 M pairs: hundreds of tiles
+    return rs_items(n) == RS_ITEMS;          // > 640 k pairs: hundreds of tiles
 }
 static inline int rs_passes(int bits) { return (bits + 7) / 8; }
 static inline uint32_t rs_tiles(uint64_t n) {

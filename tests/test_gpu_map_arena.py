@@ -16,6 +16,10 @@ def _reader(arena, q):
             q.put((seq, int(views["xyz"].shape[0]), float(views["xyz"].sum().item()), str(views["xyz"].device)))
             # drop every IPC mapping before this process ends (otherwise the producer's allocator warns that a
             # consumer died holding shared device tensors)
+            # (the Process object keeps the unpickled arguments alive and a spawned child leaves through os._exit, which runs
+            #  no destructors: drop that reference too)
+            import multiprocessing
+            multiprocessing.current_process()._args = ()
             del views, arena
             import gc
             gc.collect()
@@ -39,5 +43,8 @@ def test_device_buffers_across_processes():
     assert got == (2, 250, 1500.0, "cuda:0"), got
     del arena                      # release the exported IPC blocks before this (producer) process goes on
     import gc
-    gc.collect()
-    torch.cuda.ipc_collect()
+    import time
+    for _ in range(5):             # (the consumer's reference counts reach the producer's limbo list a moment after it exits)
+        gc.collect()
+        torch.cuda.ipc_collect()
+        time.sleep(0.05)

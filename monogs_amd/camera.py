@@ -62,17 +62,21 @@ def fused_camera_matrices(R: torch.Tensor, t: torch.Tensor, projmatrix_raw: torc
 def cached_camera_tensors(viewpoint, R: torch.Tensor, t: torch.Tensor, projmatrix_raw: torch.Tensor):
     """``fused_camera_matrices`` remembered on the viewpoint object: recomputed only when ``R``, ``t`` or the projection
     are different tensor OBJECTS from the ones the cache was made from (``update_RT`` assigns new tensors, as the
-    reference's ``Camera.update_RT`` does, utils/camera_utils.py:165-167).  ``PoseAdam.step_and_retract`` updates
+    reference's ``Camera.update_RT`` does, utils/camera_utils.py:165-167) or were edited in place by a torch op since
+    (tensor version counters).  ``PoseAdam.step_and_retract`` updates
     R, t in place and rewrites the cached tensors in the same launch, so a mapping / tracking loop launches no camera
     kernel per render.  Falls back to a plain call for objects that take no new attributes."""
     c = getattr(viewpoint, "_mgs_cam", None)
-    if c is not None and c[0] is R and c[1] is t and c[2] is projmatrix_raw:
+    if (c is not None and c[0] is R and c[1] is t and c[2] is projmatrix_raw
+            and c[4] == (R._version, t._version, projmatrix_raw._version)):
         return c[3]
     out = fused_camera_matrices(R, t, projmatrix_raw)
     ok = (R.dtype == torch.float32 and t.dtype == torch.float32 and projmatrix_raw.dtype == torch.float32
           and R.is_contiguous() and t.is_contiguous() and projmatrix_raw.is_contiguous())
     try:
-        viewpoint._mgs_cam = (R, t, projmatrix_raw, out) if ok else None
+        # (the version counters catch in-place torch edits of R / t; the fused pose step writes through raw pointers, bumps
+        #  no counter and refreshes the cached tensors itself)
+        viewpoint._mgs_cam = (R, t, projmatrix_raw, out, (R._version, t._version, projmatrix_raw._version)) if ok else None
     except AttributeError:
         pass
     return out

@@ -33,8 +33,8 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec,
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000,
-                    help="timed steps (default: ~2.4 s of GPU time at N=1, long enough for an outside utilisation sampler to see it)")
+    ap.add_argument("--steps", type=int, default=6000,
+                    help="timed steps (default: ~7 s of GPU time at N=1, longer than the 5 s period of an outside utilisation sampler)")
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--gaussians", type=int, default=2_000_000)
     ap.add_argument("--intrinsics", default="davis_1080p")

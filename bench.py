@@ -268,13 +268,19 @@ def main():
         color, radii, depth, opacity, n_touched = rasterizer(
             means3D=xyz, means2D=means2D, opacities=opac, colors_precomp=rgb, scales=scaling,     # isotropic [P,1], as MonoGS's map
             rotations=rot, theta=theta, rho=rho)
-        if stats:
+        if stats is True:
             state["walk"] = _rast.debug_blend_stats(color)
         torch.autograd.backward([color, depth], [g_color, g_depth])
         if bucket is not None and reduce:
+            if stats == "time_exchange":            # (un-timed diagnostic steps: how long the collective itself takes)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             bucket.pack()
             bucket.all_reduce()
             bucket.unpack()
+            if stats == "time_exchange":
+                e1.record()
+                state.setdefault("exchange_events", []).append((e0, e1))
         state["radii"] = radii
 
     def fence():
@@ -304,6 +310,18 @@ def main():
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+
+    # ---- N > 1: the exchange on its own (events around the collective, every rank runs it; rank 0 reports)
+    exchange = None
+    if bucket is not None:
+        for _ in range(5):
+            step(stats="time_exchange")
+        torch.cuda.synchronize()
+        ms = sorted(a.elapsed_time(b) for a, b in state["exchange_events"])
+        exchange = {"bytes": int(sum(p.numel() for p in params) * 4),
+                    "allreduce_ms": round(ms[len(ms) // 2], 4),
+                    "note": "median of 5 un-timed steps, HIP events around the collective on the launch stream; ms_per_step "
+                            "contains it in full (the gradients are complete only when the backward ends)"}
 
     # ---- per-kernel time, live, with HIP events on the launch stream (separate from the timed region)
     roof = None
@@ -430,6 +448,8 @@ def main():
                        + (" [REHEARSAL: ranks share a device, collectives over gloo]" if rehearsal else "")},
             "stages_ms": stages, "roofline": roof, "cpu_baseline": cpu, "slam": slam,
         }
+        if exchange is not None:
+            line["exchange"] = exchange
         print(json.dumps(line), flush=True)
 
 

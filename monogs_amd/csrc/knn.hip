@@ -7,7 +7,7 @@
 //
 // Two gfx950 paths, both exact and bit-identical to each other (same pair formula, the three smallest
 // distances summed in ascending order):
-//   * P < 32768 (what MonoGS calls it with: 5k-25k back-projected points per keyframe, SURVEY.md section 8a
+//   * P < 6144 (MonoGS calls it with 5k-25k back-projected points per keyframe, SURVEY.md section 8a
 //     row a12): an LDS-tiled all-pairs sweep, one query per lane, candidate tiles of 1024 points staged in LDS
 //     and read back as wave-wide broadcasts.  No index to build; < 1 ms at these sizes.
 //   * larger clouds (whole-map queries, the reference's own TODO at gaussian_model.py:293): points are
@@ -26,7 +26,8 @@ namespace mgs {
 constexpr int KNN_THREADS = 256;
 constexpr int KNN_TILE = 1024;
 constexpr int KNN_BOX = 64;                 // points per Morton box = one wave of queries
-constexpr int KNN_GRID_MIN = 32768;         // below this the all-pairs sweep wins (no sort, no index)
+constexpr int KNN_GRID_MIN = 6144;          // below this the all-pairs sweep wins (no sort, no index).  Measured, round 2:
+                                            // 4 k points 0.147 vs 0.207 ms, 8 k 0.291 vs 0.246, 16 k 0.58 vs 0.33, 32 k 1.17 vs 0.36 ms
 constexpr float KNN_FLT_MAX = 3.402823466e+38f;
 
 // the ONE pair formula both paths use (explicit fma chain so both compile to the same three instructions)

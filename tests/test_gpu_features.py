@@ -257,7 +257,9 @@ def test_capacity_mode_matches_exact_path(native_lib):
         assert not R.check_overflow()
         for x, y in zip(out_a, out_b):
             assert torch.equal(x, y)
-        assert torch.allclose(gm_a, gm_b, rtol=1e-4, atol=1e-9) and torch.allclose(gt_a, gt_b, rtol=1e-4, atol=1e-9)
+        # (two runs of the same backward differ by the order of its float atomics: absolute noise ~1e-7 of the largest entry)
+        close = lambda a, b: torch.allclose(a, b, rtol=1e-4, atol=1e-6 * float(a.abs().max()))  # noqa: E731
+        assert close(gm_a, gm_b) and close(gt_a, gt_b)
         # starve the capacity: the flag must fire, nothing may crash
         key = (20000, 640, 480)
         R._capacity_hint[key] = 1000
@@ -473,7 +475,8 @@ def test_graph_capture_of_forward_backward(native_lib):
     torch.cuda.synchronize()
     assert not R.check_overflow()
     assert torch.equal(img, img_ref)
-    assert torch.allclose(m.grad, g_ref, rtol=1e-4, atol=1e-10)
+    # (replay vs eager differ by the order of the blend backward's float atomics: absolute noise ~1e-7 of the largest entry)
+    assert torch.allclose(m.grad, g_ref, rtol=1e-4, atol=1e-6 * float(g_ref.abs().max()))
     R.clear_graph_flags()
 
 

@@ -426,6 +426,15 @@ def main():
                              "ate_rmse_m", "gaussians", "width", "height", "frames", "config", "graph_tracking", "graph_mapping")}
             slam["workload"] = "synthetic TUM-like sequence (fr3_office intrinsics), hipGraph-captured tracking and mapping iterations"
             log("slam", slam)
+            # the same loop at Replica resolution (1200x680, ~100 k Gaussians, window 10: BASELINE configs 3-4 stand-ins)
+            r2 = run_slam(n_frames=9, intrinsics="replica", tracking_itr_num=100, mapping_itr_num=150, window_size=10,
+                          kf_interval=4, init_itr_num=150, n_gaussians=150000, graph_tracking=True, graph_mapping=True)
+            slam["replica_like"] = {k: (round(v, 6 if k == "ate_rmse_m" else 3) if isinstance(v, float) else v)
+                                    for k, v in r2.items()
+                                    if k in ("tracking_fps", "tracking_iters_per_s", "mapping_iters_per_s",
+                                             "tracking_steady_iters_per_s", "mapping_steady_iters_per_s", "ate_rmse_m",
+                                             "gaussians", "width", "height", "frames")}
+            log("slam replica-like", slam["replica_like"])
         except Exception as e:          # never lose the headline line to the auxiliary measurement
             slam = {"error": repr(e)[:200]}
 

@@ -245,6 +245,12 @@ int mgs_pose_step(float* R, float* T, float* rot_delta, float* trans_delta, floa
                   int32_t flags, float* host_flag /* optional: pinned host word that also receives out[0] */,
                   const float* projmatrix_raw, float* viewmatrix, float* projmatrix, float* campos /* optional refresh */,
                   void* stream);
+/* The same update for n <= 16 independent viewpoints in ONE launch (the keyframes of a mapping window,
+ * /root/reference/utils/slam_mapper.py:486-496).  `ptrs`: HOST array of n x 18 device pointers in the order of mgs_pose_step's
+ * pointer arguments (R, T, rot_delta, trans_delta, exposure_a, exposure_b, grad_rot, grad_trans, grad_a, grad_b, adam_m, adam_v,
+ * step_counter [required], out, projmatrix_raw, viewmatrix, projmatrix, campos; NULL where optional); the scalars are shared. */
+int mgs_pose_step_batch(int32_t n, void* const* ptrs, float lr_rot, float lr_trans, float lr_exposure, float beta1,
+                        float beta2, float eps, float converged_threshold, int32_t flags, void* stream);
 
 /* ---- Keyframe back-projection ------------------------------------------------
  * The per-point part of GaussianModel.create_viewpoint_pcd (/root/reference/gaussian_splatting/scene/gaussian_model.py:121-319)

@@ -66,6 +66,7 @@ SIGNATURES = {
     "mgs_camera_setup": (C.c_int, [C.c_void_p] * 7),
     "mgs_pose_step": (C.c_int, [C.c_void_p] * 12 + [C.c_int32] + [C.c_float] * 7
                       + [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p] + [C.c_void_p] * 4 + [C.c_void_p]),
+    "mgs_pose_step_batch": (C.c_int, [C.c_int32, C.POINTER(C.c_void_p)] + [C.c_float] * 7 + [C.c_int32, C.c_void_p]),
     "mgs_adam_step": (C.c_int, [C.c_int32] + [C.c_void_p] * 6 + [C.c_double] * 3 + [C.c_int32, C.c_void_p, C.c_void_p]),
     "mgs_densify_stats": (C.c_int, [C.c_int32] + [C.c_void_p] * 6),
     "mgs_sum_buffers": (C.c_int, [C.c_int32, C.POINTER(C.c_void_p), C.c_void_p, C.c_uint64, C.c_void_p]),

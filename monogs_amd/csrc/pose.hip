@@ -68,8 +68,7 @@ __global__ void camera_setup_kernel(const float* __restrict__ R, const float* __
     camera_entry(R, T, proj_T, (int)threadIdx.x, view_T, full_T, campos);
 }
 
-__global__ void pose_step_kernel(PoseStepArgs a) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__device__ __forceinline__ void pose_step_one(const PoseStepArgs& a) {
     // Sticky convergence: the reference's tracker leaves its loop at the first converged update
     // (/root/reference/utils/slam_tracker.py:172-176).  With the loop replayed from a hipGraph the host learns of the
     // convergence one replay late; making that extra replay a no-op keeps the result identical to the early exit.
@@ -137,6 +136,20 @@ __global__ void pose_step_kernel(PoseStepArgs a) {
     }
 }
 
+__global__ void pose_step_kernel(PoseStepArgs a) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    pose_step_one(a);
+}
+
+// The pose steps of ALL the keyframes of a mapping window in one launch (one workgroup each; they are independent): a window
+// of eight used to end its iteration with seven dependent 7-us launches.
+constexpr int POSE_BATCH_MAX = 16;
+struct PoseBatchArgs { PoseStepArgs v[POSE_BATCH_MAX]; };
+__global__ void pose_step_batch_kernel(PoseBatchArgs b) {
+    if (threadIdx.x != 0) return;
+    pose_step_one(b.v[blockIdx.x]);
+}
+
 }  // namespace mgs
 
 using namespace mgs;
@@ -150,13 +163,12 @@ extern "C" int mgs_camera_setup(const float* R, const float* T, const float* pro
     return 0;
 }
 
-extern "C" int mgs_pose_step(float* R, float* T, float* rot_delta, float* trans_delta, float* exposure_a,
-                             float* exposure_b, const float* grad_rot, const float* grad_trans, const float* grad_a,
-                             const float* grad_b, float* adam_m, float* adam_v, int32_t step, float lr_rot,
-                             float lr_trans, float lr_exposure, float beta1, float beta2, float eps,
-                             float converged_threshold, int32_t* step_counter, float* out, int32_t flags,
-                             float* host_flag, const float* projmatrix_raw, float* viewmatrix, float* projmatrix,
-                             float* campos, void* stream) {
+static int fill_pose_args(PoseStepArgs& a, float* R, float* T, float* rot_delta, float* trans_delta, float* exposure_a,
+                          float* exposure_b, const float* grad_rot, const float* grad_trans, const float* grad_a,
+                          const float* grad_b, float* adam_m, float* adam_v, int32_t step, float lr_rot, float lr_trans,
+                          float lr_exposure, float beta1, float beta2, float eps, float converged_threshold,
+                          int32_t* step_counter, float* out, int32_t flags, float* host_flag, const float* projmatrix_raw,
+                          float* viewmatrix, float* projmatrix, float* campos) {
     if (!R || !T || !rot_delta || !trans_delta || !adam_m || !adam_v || !out) {
         set_error("R, T, rot_delta, trans_delta, adam_m, adam_v, out must be non-NULL");
         return 1;
@@ -166,13 +178,50 @@ extern "C" int mgs_pose_step(float* R, float* T, float* rot_delta, float* trans_
         set_error("camera refresh needs projmatrix_raw, viewmatrix, projmatrix and campos");
         return 1;
     }
-    PoseStepArgs a;
     a.R = R; a.T = T; a.rot_delta = rot_delta; a.trans_delta = trans_delta; a.exp_a = exposure_a; a.exp_b = exposure_b;
     a.g_rot = grad_rot; a.g_trans = grad_trans; a.g_a = grad_a; a.g_b = grad_b; a.m = adam_m; a.v = adam_v; a.out = out;
     a.lr_rot = lr_rot; a.lr_trans = lr_trans; a.lr_exp = lr_exposure; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
     a.converged_threshold = converged_threshold; a.step = step; a.step_dev = step_counter; a.flags = flags; a.host_flag = host_flag;
     a.proj_T = projmatrix_raw; a.view_T = viewmatrix; a.full_T = projmatrix; a.campos = campos;
+    return 0;
+}
+
+extern "C" int mgs_pose_step(float* R, float* T, float* rot_delta, float* trans_delta, float* exposure_a,
+                             float* exposure_b, const float* grad_rot, const float* grad_trans, const float* grad_a,
+                             const float* grad_b, float* adam_m, float* adam_v, int32_t step, float lr_rot,
+                             float lr_trans, float lr_exposure, float beta1, float beta2, float eps,
+                             float converged_threshold, int32_t* step_counter, float* out, int32_t flags,
+                             float* host_flag, const float* projmatrix_raw, float* viewmatrix, float* projmatrix,
+                             float* campos, void* stream) {
+    PoseStepArgs a;
+    if (fill_pose_args(a, R, T, rot_delta, trans_delta, exposure_a, exposure_b, grad_rot, grad_trans, grad_a, grad_b, adam_m,
+                       adam_v, step, lr_rot, lr_trans, lr_exposure, beta1, beta2, eps, converged_threshold, step_counter, out,
+                       flags, host_flag, projmatrix_raw, viewmatrix, projmatrix, campos)) return 1;
     hipLaunchKernelGGL(pose_step_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a);
+    MGS_HIP(hipGetLastError());
+    return 0;
+}
+
+// n <= 16 independent pose steps in one launch.  `ptrs` is a HOST array of n x 18 device pointers in the order of
+// mgs_pose_step's pointer arguments: R, T, rot_delta, trans_delta, exposure_a, exposure_b, grad_rot, grad_trans, grad_a,
+// grad_b, adam_m, adam_v, step_counter, out, projmatrix_raw, viewmatrix, projmatrix, campos (NULL where optional).
+// The scalars are shared by the batch (the keyframes of a window use the same learning rates).
+extern "C" int mgs_pose_step_batch(int32_t n, void* const* ptrs, float lr_rot, float lr_trans, float lr_exposure, float beta1,
+                                   float beta2, float eps, float converged_threshold, int32_t flags, void* stream) {
+    if (n < 0 || n > POSE_BATCH_MAX || (n > 0 && !ptrs)) { set_error("mgs_pose_step_batch: 0..16 poses"); return 1; }
+    if (n == 0) return 0;
+    PoseBatchArgs b;
+    for (int i = 0; i < n; ++i) {
+        void* const* q = ptrs + (size_t)i * 18;
+        if (!q[12]) { set_error("mgs_pose_step_batch needs device step counters"); return 1; }
+        if (fill_pose_args(b.v[i], (float*)q[0], (float*)q[1], (float*)q[2], (float*)q[3], (float*)q[4], (float*)q[5],
+                           (const float*)q[6], (const float*)q[7], (const float*)q[8], (const float*)q[9], (float*)q[10],
+                           (float*)q[11], 0, lr_rot, lr_trans, lr_exposure, beta1, beta2, eps, converged_threshold,
+                           (int32_t*)q[12], (float*)q[13], flags, nullptr, (const float*)q[14], (float*)q[15], (float*)q[16],
+                           (float*)q[17])) return 1;
+    }
+    for (int i = n; i < POSE_BATCH_MAX; ++i) b.v[i] = b.v[0];
+    hipLaunchKernelGGL(pose_step_batch_kernel, dim3(n), dim3(64), 0, (hipStream_t)stream, b);
     MGS_HIP(hipGetLastError());
     return 0;
 }

@@ -192,14 +192,15 @@ class WindowMapper:
                 gmap.optimizer.step()
                 gmap.optimizer.zero_grad(set_to_none=True)
                 gmap.update_learning_rate(self.nr_iters)
+                moved = []
                 for k in mine:
                     vp = viewpoints[k]
                     po = self._pose_optimizer(vp)
-                    if vp.frame_idx == 0:             # the first frame is the gauge: never moved
-                        po.zero_grad()
-                        continue
-                    po.step_and_retract(sync=False)
-                    po.zero_grad()
+                    if vp.frame_idx != 0:             # the first frame is the gauge: never moved
+                        moved.append(po)
+                PoseAdam.step_batch(moved)            # the owned keyframes' pose steps in one launch
+                for k in mine:
+                    self._pose_optimizer(viewpoints[k]).zero_grad()
         return gaussian_split
 
     # ---- collectives ------------------------------------------------------------------------------------------------

@@ -69,3 +69,42 @@ class PoseAdam:
                                          _stream()),
                        "mgs_pose_step")
         return bool(self.out[0].item() > 0.5) if sync else self.out
+
+    def _pointers(self):
+        """The 18 device pointers of this optimiser's update, in ``mgs_pose_step_batch`` order."""
+        vp = self.vp
+        if not vp.R.is_contiguous() or not vp.T.is_contiguous():
+            vp.R, vp.T = vp.R.contiguous(), vp.T.contiguous()
+        cam = (None,) * 4
+        c = getattr(vp, "_mgs_cam", None)
+        if c is not None and c[0] is vp.R and c[1] is vp.T:
+            cam = (c[2].data_ptr(),) + tuple(t.data_ptr() for t in c[3])
+        g = lambda p: None if p.grad is None else p.grad.contiguous().data_ptr()  # noqa: E731
+        return (vp.R.data_ptr(), vp.T.data_ptr(), vp.cam_rot_delta.data_ptr(), vp.cam_trans_delta.data_ptr(),
+                vp.exposure_a.data_ptr(), vp.exposure_b.data_ptr(), g(vp.cam_rot_delta), g(vp.cam_trans_delta),
+                g(vp.exposure_a), g(vp.exposure_b), self.m.data_ptr(), self.v.data_ptr(), self.t_dev.data_ptr(),
+                self.out.data_ptr()) + cam
+
+    @staticmethod
+    @torch.no_grad()
+    def step_batch(optimisers, converged_threshold=1e-4):
+        """``step_and_retract(sync=False)`` of several viewpoints in ONE launch (the keyframes of a mapping window; they must
+        share learning rates, betas and eps, as the reference's parameter groups do, utils/slam_mapper.py:687-717).  Groups of
+        16."""
+        import ctypes as C
+        optimisers = list(optimisers)
+        if not optimisers:
+            return
+        lib = _lib.load()
+        o0 = optimisers[0]
+        for o in optimisers[1:]:
+            if (o.lrs, o.betas, o.eps, o.sticky) != (o0.lrs, o0.betas, o0.eps, o0.sticky):
+                raise ValueError("step_batch: the optimisers must share learning rates, betas, eps and the sticky flag")
+        with _device_guard(o0.m.device):
+            for i in range(0, len(optimisers), 16):
+                grp = optimisers[i:i + 16]
+                flat = [x for o in grp for x in o._pointers()]
+                arr = (C.c_void_p * len(flat))(*flat)
+                _lib.check(lib.mgs_pose_step_batch(len(grp), arr, o0.lrs[0], o0.lrs[1], o0.lrs[2], o0.betas[0], o0.betas[1],
+                                                   o0.eps, float(converged_threshold), 1 if o0.sticky else 0, _stream()),
+                           "mgs_pose_step_batch")

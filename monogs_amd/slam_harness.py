@@ -337,8 +337,8 @@ def run_slam(n_frames=12, intrinsics="fr3_office", tracking_itr_num=100, mapping
             with torch.no_grad():
                 gmap.optimizer.step()
                 gmap.optimizer.zero_grad(set_to_none=True)
+                PoseAdam.step_batch(fused_kf)                   # every keyframe pose of the window in one launch
                 for pa in fused_kf:
-                    pa.step_and_retract(sync=False)
                     pa.zero_grad()
 
         if graph_mapping and fused_pose_on and fused_losses_on and iters >= 8:

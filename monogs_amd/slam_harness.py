@@ -313,17 +313,21 @@ def run_slam(n_frames=12, intrinsics="fr3_office", tracking_itr_num=100, mapping
                         outs += [color, depth]
                         grads += [lg.d_render, lg.d_depth]
                         lgs.append((vp, lg))
-                    if use_streams:
-                        for st in kf_streams[:len(window)]:
-                            main.wait_stream(st)
+                    joined = not use_streams
                 else:
+                    joined = True
                     for vp in window:
                         pkg = _render(vp, intr, gmap, bg)
                         lg = fused_losses.loss_grads(pkg["render"], pkg["depth"], None, vp, tracking=False, init=init)
                         outs += [pkg["render"], pkg["depth"]]
                         grads += [lg.d_render, lg.d_depth]
                         lgs.append((vp, lg))
+                # (no join before the backward: every keyframe's backward runs on the stream of its forward, behind it, and the
+                #  node that adds the gradients up waits for all of them; the join comes before the optimiser steps)
                 torch.autograd.backward(outs, grads)
+                if not joined:
+                    for st in kf_streams[:len(window)]:
+                        torch.cuda.current_stream().wait_stream(st)
                 for vp, lg in lgs:
                     if lg.has_exposure:
                         vp.exposure_a.grad, vp.exposure_b.grad = lg.d_exposure_a, lg.d_exposure_b

@@ -110,7 +110,7 @@ class GaussianMap:
         groups = [{"params": [p], "lr": lr, "name": n} for p, lr, n in zip(self.params(), self.lrs, NAMES)]
         try:       # one multi-tensor kernel per step (the reference uses the default, unfused Adam)
             return torch.optim.Adam(groups, eps=1e-15, fused=True, capturable=self.capturable)
-        except Exception:
+        except (RuntimeError, TypeError, ValueError):      # this torch build has no fused Adam for the device / dtype
             return torch.optim.Adam(groups, eps=1e-15, capturable=self.capturable)
 
     def _torch_extend(self, new):

@@ -21,6 +21,7 @@ namespace mgs {
 constexpr int LS_THREADS = 256;
 constexpr int LS_MAX_BLOCKS = 256;      // forward reduction: two stages, no atomics (64 workgroups were latency-bound: 26 us at VGA)
 // scratch: 16 floats of results followed by LS_MAX_BLOCKS x 8 floats of per-workgroup partial sums
+constexpr int LP_SUMS = 7;          // per-workgroup partial sums: s_rgb, c_rgb, s_d, c_d, s_op, u_a, u_b
 enum : int { LP_L1_RGB = 6, LP_L1_D = 7, LP_SCALE_RGB = 8, LP_SCALE_D = 9, LP_DAB = 10, LP_LOSS = 12, LP_UA = 13, LP_UB = 14, LP_N = 16, LP_PART = 8 };
 // scratch[LP_DAB .. LP_DAB+1]: d(exposure_a), d(exposure_b) of the fused value + gradients call.  The exposure gradients are
 // SUMS over the pixels of terms that differ from the forward's only by a scalar factor (the loss scale): the forward kernel
@@ -34,16 +35,6 @@ struct LossArgs {
     int W, H, tracking, init;
     float lambda_rgb;
 };
-
-__device__ __forceinline__ float block_sum(float v, float* smem) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    __syncthreads();
-    if (lane == 0) smem[wv] = v;
-    __syncthreads();
-    return (smem[0] + smem[1]) + (smem[2] + smem[3]);
-}
 
 __device__ __forceinline__ float sgn(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }
 
@@ -76,7 +67,6 @@ __device__ __forceinline__ void fwd_pixel(const LossArgs& a, float ea, float eb,
 // thread then has all its loads in flight at once instead of ~11 dependent-latency scalar loads per pixel.
 template <bool VEC4>
 __global__ void __launch_bounds__(LS_THREADS) loss_forward_kernel(LossArgs a, float* __restrict__ part) {
-    __shared__ float smem[4];
     const size_t HW = (size_t)a.W * a.H;
     const float ea = a.init ? 1.f : __expf(a.exp_a[0]), eb = a.init ? 0.f : a.exp_b[0];
     FwdAcc acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -102,12 +92,23 @@ __global__ void __launch_bounds__(LS_THREADS) loss_forward_kernel(LossArgs a, fl
                       a.tracking ? a.opacity[p] : 0.f, a.render[p], a.render[HW + p], a.render[2 * HW + p], a.gt_rgb[p],
                       a.gt_rgb[HW + p], a.gt_rgb[2 * HW + p], a.depth[p], acc);
     }
-    const float s_rgb = block_sum(acc.s_rgb, smem), c_rgb = block_sum(acc.c_rgb, smem);
-    const float s_d = block_sum(acc.s_d, smem), c_d = block_sum(acc.c_d, smem), s_op = block_sum(acc.s_op, smem);
-    const float u_a = block_sum(acc.u_a, smem), u_b = block_sum(acc.u_b, smem);
-    if (threadIdx.x == 0) {
-        float* o = part + LP_N + (size_t)blockIdx.x * LP_PART;
-        o[0] = s_rgb; o[1] = c_rgb; o[2] = s_d; o[3] = c_d; o[4] = s_op; o[5] = u_a; o[6] = u_b;
+    // the seven sums of the workgroup with ONE pair of barriers (wave sums by shuffles, the four waves' sums through LDS, added
+    // in the order ((w0 + w1) + (w2 + w3)) by seven threads)
+    float v7[LP_SUMS] = {acc.s_rgb, acc.c_rgb, acc.s_d, acc.c_d, acc.s_op, acc.u_a, acc.u_b};
+#pragma unroll
+    for (int k = 0; k < LP_SUMS; ++k)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v7[k] += __shfl_xor(v7[k], o, 64);
+    __shared__ float s_w[4][LP_SUMS];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < LP_SUMS; ++k) s_w[wv][k] = v7[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < LP_SUMS) {
+        const int k = threadIdx.x;
+        part[LP_N + (size_t)blockIdx.x * LP_PART + k] = (s_w[0][k] + s_w[1][k]) + (s_w[2][k] + s_w[3][k]);
     }
 }
 
@@ -136,7 +137,6 @@ __device__ __forceinline__ LossScalars loss_scalars(const LossArgs& a, const flo
 }
 
 // one wave: sum the per-workgroup partials in a fixed order (lane l adds blocks l, l+64, ...: bitwise reproducible)
-constexpr int LP_SUMS = 7;
 __device__ __forceinline__ void sum_partials(const float* __restrict__ part, int nblocks, int lane, float v[LP_SUMS]) {
 #pragma unroll
     for (int k = 0; k < LP_SUMS; ++k) v[k] = 0.f;

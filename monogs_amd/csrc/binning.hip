@@ -225,7 +225,8 @@ __global__ void __launch_bounds__(256) duplicate_kernel(int P, const uint2* __re
         const uint32_t n_waves = (uint32_t)n_threads / WAVE;
         const uint32_t CH = (((R_emit + n_waves - 1u) / n_waves) + 63u) & ~63u;
         const uint32_t wave_id = (uint32_t)blockIdx.x * 4u + (uint32_t)wv;
-        const uint32_t s0 = min(R_emit, wave_id * CH), s1 = min(R_emit, s0 + CH);
+        const uint64_t s0w = (uint64_t)wave_id * CH;                             // (64-bit: wave_id * CH may pass 2^32 for R near 2^32)
+        const uint32_t s0 = s0w < (uint64_t)R_emit ? (uint32_t)s0w : R_emit, s1 = (uint64_t)s0 + CH < (uint64_t)R_emit ? s0 + CH : R_emit;
         auto incl = [&](uint32_t k) { return offsets[k] + (offsets_global ? 0u : block_sums[k / SCAN_ITEMS]); };
         uint32_t g = 0;
         if (s0 < s1) {      // smallest g with incl(g) > s0: it exists because incl(P - 1) = R_all > s0

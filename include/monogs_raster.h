@@ -192,7 +192,9 @@ int mgs_dist2_knn(int32_t P, const float* points /* [P,3] */, float* out /* [P] 
 
 /* ---- Fused SLAM losses (caller-side widening) --------------------------------
  * Forward value + analytic gradients of get_loss_mapping (/root/reference/utils/slam_utils.py:101-146,
- * tracking = 0) and get_loss_tracking (:58-98, tracking = 1).  render[3,H,W], depth[1,H,W], opacity[1,H,W]
+ * mode = 0) and get_loss_tracking (:58-98, mode & MGS_LOSS_TRACKING).  MGS_LOSS_INVERT_DEPTH selects the reference's
+ * `invert_depth=True` branch (:83-88, :138-141): the depth term compares 1 / (depth + eps) with 1 / (gt_depth + eps),
+ * eps = 1e-6 in the tracking loss and 0 in the mapping loss, exactly as the reference writes the two.  render[3,H,W], depth[1,H,W], opacity[1,H,W]
  * (tracking only), gt_rgb[3,H,W], gt_depth[H,W]; mask / grad_mask are [H,W] bytes (0 / non-zero; mask may be
  * NULL = all ones); exposure_a / exposure_b are device scalars (ignored when init != 0: rgb = render).
  * mgs_loss_forward writes the scalar loss to loss_out [device] and keeps its sums in `scratch`
@@ -201,15 +203,17 @@ int mgs_dist2_knn(int32_t P, const float* points /* [P,3] */, float* out /* [P] 
  * The opacity image gets no gradient (the rasteriser ignores dL/dopacity).
  * d_exposure is STORED (scale x the unscaled sums the forward kept in its per-workgroup partials: no atomics, no clear,
  * bitwise reproducible); it may be the two floats at scratch + MGS_LOSS_SCRATCH_DAB. */
+#define MGS_LOSS_TRACKING 1
+#define MGS_LOSS_INVERT_DEPTH 2
 #define MGS_LOSS_SCRATCH_DAB 10
 #define MGS_LOSS_SCRATCH_LOSS 12
 size_t mgs_loss_scratch_bytes(void);
-int mgs_loss_forward(int32_t width, int32_t height, int32_t tracking, int32_t init, float lambda_rgb,
+int mgs_loss_forward(int32_t width, int32_t height, int32_t mode, int32_t init, float lambda_rgb,
                      const float* render, const float* depth, const float* opacity, const float* gt_rgb,
                      const float* gt_depth, const uint8_t* mask, const uint8_t* grad_mask,
                      const float* exposure_a, const float* exposure_b, float* scratch, float* loss_out,
                      void* stream);
-int mgs_loss_backward(int32_t width, int32_t height, int32_t tracking, int32_t init, float lambda_rgb,
+int mgs_loss_backward(int32_t width, int32_t height, int32_t mode, int32_t init, float lambda_rgb,
                       const float* render, const float* depth, const float* opacity, const float* gt_rgb,
                       const float* gt_depth, const uint8_t* mask, const uint8_t* grad_mask,
                       const float* exposure_a, const float* exposure_b, const float* scratch,
@@ -218,7 +222,7 @@ int mgs_loss_backward(int32_t width, int32_t height, int32_t tracking, int32_t i
  * (torch.autograd.backward([color, depth], [d_render, d_depth])) instead of building an autograd node for the scalar:
  * no finalize kernel, no ones-fill.  Afterwards scratch[MGS_LOSS_SCRATCH_LOSS] holds the loss value and
  * scratch[MGS_LOSS_SCRATCH_DAB .. +1] hold dL/d(exposure_a), dL/d(exposure_b) (unless `init`). */
-int mgs_loss_grads(int32_t width, int32_t height, int32_t tracking, int32_t init, float lambda_rgb,
+int mgs_loss_grads(int32_t width, int32_t height, int32_t mode, int32_t init, float lambda_rgb,
                    const float* render, const float* depth, const float* opacity, const float* gt_rgb,
                    const float* gt_depth, const uint8_t* mask, const uint8_t* grad_mask,
                    const float* exposure_a, const float* exposure_b, float* scratch, float* d_render, float* d_depth,

@@ -196,6 +196,9 @@ static int forward_render_impl(const mgs_camera* cam, int32_t P, uint64_t R, boo
     if (P > 0 && (!geometry || !n_touched)) { set_error("geometry and n_touched must be non-NULL"); return 1; }
     if (R > 0 && !binning) { set_error("binning scratch is NULL"); return 1; }
     if (R >= (1ull << 32)) { set_error("num_rendered exceeds 2^32-1"); return 1; }
+    // No Gaussians: nothing was preprocessed (geometry may be NULL, its digit table was never cleared), so nothing may be
+    // sorted whatever capacity the caller passed -- the kernels below then only clear the ranges and render the background.
+    if (P == 0) R = 0;
     hipStream_t s = (hipStream_t)stream;
     const int W = cam->image_width, H = cam->image_height;
     GeometryState g = GeometryState::carve(geometry, P);
@@ -321,6 +324,7 @@ int mgs_debug_set_radix_spin_limit(uint32_t limit) { return set_radix_spin_limit
 int mgs_debug_set_option(const char* name, int64_t value) {
     if (name && !strcmp(name, "radix_scanned")) { g_opt_radix_scanned = (int)value; return 0; }
     if (name && !strcmp(name, "dup_slot_major")) { g_opt_dup_slot_major = (int)value; return 0; }
+    if (name && !strcmp(name, "blend_bwd_transposed")) { g_opt_blend_bwd_transposed = (int)value; return 0; }
     if (name && !strcmp(name, "scan_small")) { g_opt_scan_small = (int)value; return 0; }
     if (name && !strcmp(name, "knn_grid_min")) { g_opt_knn_grid_min = value > 0x7FFFFFFF ? 0x7FFFFFFF : (int)value; return 0; }
     set_error("mgs_debug_set_option: unknown option");

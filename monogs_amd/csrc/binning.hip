@@ -408,7 +408,9 @@ int launch_depth_sort(const GeometryState& g, int P, hipStream_t s) {
 }
 
 int launch_sort(const GeometryState& g, const BinningState& b, uint64_t R, int bits, hipStream_t s, const uint32_t* n_dev) {
-    // the scratch was cleared by duplicate_kernel, which also counted the digits of the keys it emitted (small sorts)
+    if (R == 0) return 0;
+    // the scratch was cleared by duplicate_kernel, which also counted the digits of the keys it emitted (small sorts; the
+    // same predicate as launch_duplicate's `count_digits` -- R > 0 implies P > 0, forward_render_impl)
     const bool counted = bits <= 16 && radix_wants_hist(R) && g.tile_hist != nullptr;
     return radix_sort_pairs(b.keys_a, b.vals_a, b.keys_b, b.vals_b, R, bits, b.sort_temp, s, n_dev, true, nullptr, nullptr,
                             counted ? g.tile_hist : nullptr);

@@ -401,6 +401,282 @@ __global__ void __launch_bounds__(256) blend_backward_kernel(BlendArgs a, int nt
     }
 }
 
+// =================================================================================================
+// backward, "transposed" variant (round 3): no 64-lane reduction per survivor.
+//
+// The walk, the cull and the per-pixel arithmetic are those of blend_backward_kernel.  What changes is where the ten
+// per-Gaussian sums are formed.  There, every surviving (instance, quadrant) pair pays a packed 64-lane reduction of ten
+// values: 7 v_permlane*_swap (3.5 ns of SIMD issue each, tools/ubench/valu_rate.hip), 20 adds, 13 LDS-crossbar exchanges,
+// 2 selects -- 55-60 ns of the ~125 ns a survivor costs.  Here a survivor only leaves its two per-pixel factors
+//     h = G dL/dalpha        (geometry: the six raw moments are h x {dx, dy, dx^2, dx dy, dy^2, 1})
+//     w = alpha T            (colour / depth: w x dL/dpixel)
+// in a 4-slot slab of LDS (two ds_write_b32, lane = pixel).  Every fourth survivor the wave turns round: row r (16 lanes)
+// of the wave takes slot r, lane q of the row takes the 4 horizontally adjacent pixels 4q..4q+3 of the quadrant (one
+// ds_read_b128 per factor), forms the ten sums over ITS four pixels -- dy is shared by the four, dx steps by one, so the
+// moments cost 17 plain VALU and the colours 16 -- and the 16 lanes of a row are then added up by a packed DPP butterfly
+// (21 full-rate v_add_f32_dpp: the first two stages halve the register count with bank masks, row_ror:8 / row_half_mirror;
+// the last two are quad permutes), which leaves the ten sums of the row's Gaussian in ten lanes of the row.  ONE atomic
+// instruction then covers the four 64-byte gradient lines of the batch (40 active lanes, one memory-side request per
+// line, as before).  Per survivor: ~10 + 11 VALU instead of ~29 expensive ones, nothing on the LDS crossbar, and the
+// transposition is exact (same products, different summation order).
+// =================================================================================================
+constexpr int BT_SLOTS = 4;                      // survivors per batch = rows of 16 lanes
+// which gradient slot the lane (t = lane & 15) of a row holds after reduce_rows (see there); -1: none
+__device__ __forceinline__ int bt_slot10(int t) {
+    const int bank = t >> 2, m = t & 3;
+    if (m == 0) return bank == 3 ? 0 : bank == 1 ? 1 : bank == 2 ? 2 : 3;
+    if (m == 1) return bank == 3 ? 4 : bank == 1 ? 5 : bank == 2 ? 6 : 7;
+    if (m == 2) return bank == 3 ? 8 : bank == 1 ? 9 : -1;
+    return -1;
+}
+__device__ __forceinline__ int bt_slot6(int t) {          // pose-only: v0..v5 = {SX, SY, SXX, SXY, SYY, DDEPTH}
+    const int bank = t >> 2, m = t & 3;
+    if (m == 0) return bank == 3 ? G_SX : bank == 1 ? G_SY : bank == 2 ? G_SXX : G_SXY;
+    if (m == 1) return bank == 3 ? G_SYY : bank == 1 ? G_DDEPTH : -1;
+    return -1;
+}
+// Sum ten values over the 16 lanes of every row.  On return lane t of a row holds, in the returned register,
+//   t & 3 == 0:  bank 3: v0, bank 1: v1, bank 2: v2, bank 0: v3     (bank = t >> 2)
+//   t & 3 == 1:  bank 3: v4, bank 1: v5, bank 2: v6, bank 0: v7
+//   t & 3 == 2:  bank 3: v8, bank 1: v9
+// Stage A (partner t ^ 8) packs two values into one register with the DPP bank mask (banks 2, 3 = lanes with bit 3 set take
+// the first value, banks 0, 1 the second); stage B (partner 7 - (t & 7) in the same half row: opposite bit 2) packs again
+// (banks 1, 3 / 0, 2); stages C, D add up the quads.  One asm block: the instructions are ordered so that no DPP operand
+// was written by either of the two preceding instructions (the VALU -> DPP read hazard needs two wait states and the
+// compiler does not look inside inline asm); the s_nop covers the block's inputs.
+__device__ __forceinline__ float reduce_rows10(float v0, float v1, float v2, float v3, float v4, float v5, float v6,
+                                               float v7, float v8, float v9, unsigned long long m1, unsigned long long m2) {
+    float a0, a1, a2, a3, a4;
+    asm volatile(
+        "s_nop 1\n\t"
+        // stage A: (v0, v1) -> a0, (v2, v3) -> a1, (v4, v5) -> a2, (v6, v7) -> a3, (v8, v9) -> a4
+        "v_add_f32_dpp %0, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %1, %7, %7 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %2, %9, %9 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %3, %11, %11 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %4, %13, %13 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %0, %6, %6 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %1, %8, %8 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %2, %10, %10 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %3, %12, %12 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %4, %14, %14 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        // stage B: (a0, a1) -> v0's register ... the inputs are dead: reuse %5 (b0), %6 (b1), %7 (b2)
+        "v_add_f32_dpp %5, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %6, %2, %2 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %5, %1, %1 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %6, %3, %3 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %7, %4, %4 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        // stage C: quad_perm [2,3,0,1]
+        "v_add_f32_dpp %0, %5, %5 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %6, %6 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %7, %7 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        // stage D: quad_perm [1,0,3,2]
+        "v_add_f32_dpp %5, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %6, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %7, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(a4), "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5),
+          "+v"(v6), "+v"(v7), "+v"(v8), "+v"(v9));
+    // v0 = {v0..v3 by bank}, v1 = {v4..v7 by bank}, v2 = {v8 | v9}: lane t & 3 picks 0 -> v0, 1 -> v1, else v2
+    const float r12 = __builtin_amdgcn_inverse_ballot_w64(m1) ? v1 : v2;
+    return __builtin_amdgcn_inverse_ballot_w64(m2) ? v0 : r12;
+}
+// six values (pose-only): stage A (v0, v1) -> a0, (v2, v3) -> a1, (v4, v5) -> a2; stage B (a0, a1) -> b0, a2 -> b1
+//   t & 3 == 0:  bank 3: v0, bank 1: v1, bank 2: v2, bank 0: v3;   t & 3 == 1:  banks 2, 3: v4, banks 0, 1: v5
+__device__ __forceinline__ float reduce_rows6(float v0, float v1, float v2, float v3, float v4, float v5,
+                                              unsigned long long m2) {
+    float a0, a1, a2;
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %1, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %2, %7, %7 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %0, %4, %4 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %1, %6, %6 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %2, %8, %8 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %3, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %3, %1, %1 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %4, %2, %2 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %4, %4 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %3, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %4, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        : "=&v"(a0), "=&v"(a1), "=&v"(a2), "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5));
+    return __builtin_amdgcn_inverse_ballot_w64(m2) ? v0 : v1;
+}
+
+struct __attribute__((aligned(16))) BtMetaRec { float x, y; uint32_t g; };
+// What a lane needs to turn a batch round (all by value: a by-reference lambda ended up as a closure object in scratch).
+struct BtLane {
+    const float *fh, *fw, *fp;      // this wave's factor slabs; this lane's dL/dpixel block [rgb, depth][4 pixels] (LDS)
+    const BtMetaRec* fm;            // the metadata {centre x, centre y, Gaussian index} of this lane's row (LDS)
+    int lane, q;
+    float u0, v0;
+    uint32_t slot_bytes;
+    unsigned long long m_out, m_q0, m_q1;
+    float* grad_acc;
+};
+template <bool POSE_ONLY>
+__device__ __forceinline__ void bt_flush(const BtLane L, int n) {
+    const int lane = L.lane, q = L.q;
+    const float4 h4 = *reinterpret_cast<const float4*>(L.fh + (lane >> 4) * WAVE + 4 * q);
+    const float4 w4 = *reinterpret_cast<const float4*>(L.fw + (lane >> 4) * WAVE + 4 * q);
+    const BtMetaRec me = *L.fm;
+    const float dy = me.y - L.v0;
+    const float dx0 = me.x - L.u0, dx1 = dx0 - 1.f, dx2 = dx0 - 2.f, dx3 = dx0 - 3.f;
+    const float hx0 = h4.x * dx0, hx1 = h4.y * dx1, hx2 = h4.z * dx2, hx3 = h4.w * dx3;
+    const float H0 = (h4.x + h4.y) + (h4.z + h4.w);
+    const float H1 = (hx0 + hx1) + (hx2 + hx3);
+    const float H2 = __builtin_fmaf(hx3, dx3, __builtin_fmaf(hx2, dx2, __builtin_fmaf(hx1, dx1, hx0 * dx0)));
+    const float s_y = dy * H0, s_xy = dy * H1, s_yy = dy * s_y;
+    float m;
+    if (POSE_ONLY) {
+        const float4 c3 = *reinterpret_cast<const float4*>(L.fp);
+        const float s_z = __builtin_fmaf(w4.w, c3.w, __builtin_fmaf(w4.z, c3.z, __builtin_fmaf(w4.y, c3.y, w4.x * c3.x)));
+        m = reduce_rows6(H1, s_y, H2, s_xy, s_yy, s_z, L.m_q0);
+    } else {
+        const float4 c0 = *reinterpret_cast<const float4*>(L.fp), c1 = *reinterpret_cast<const float4*>(L.fp + 4),
+                     c2 = *reinterpret_cast<const float4*>(L.fp + 8), c3 = *reinterpret_cast<const float4*>(L.fp + 12);
+        const float s_r = __builtin_fmaf(w4.w, c0.w, __builtin_fmaf(w4.z, c0.z, __builtin_fmaf(w4.y, c0.y, w4.x * c0.x)));
+        const float s_g = __builtin_fmaf(w4.w, c1.w, __builtin_fmaf(w4.z, c1.z, __builtin_fmaf(w4.y, c1.y, w4.x * c1.x)));
+        const float s_b = __builtin_fmaf(w4.w, c2.w, __builtin_fmaf(w4.z, c2.z, __builtin_fmaf(w4.y, c2.y, w4.x * c2.x)));
+        const float s_z = __builtin_fmaf(w4.w, c3.w, __builtin_fmaf(w4.z, c3.z, __builtin_fmaf(w4.y, c3.y, w4.x * c3.x)));
+        m = reduce_rows10(H1, s_y, H2, s_xy, s_yy, H0, s_r, s_g, s_b, s_z, L.m_q1, L.m_q0);
+    }
+    // rows >= n hold a stale slot: masked out.  One instruction, <= 40 active lanes, one 64-byte request per gradient line.
+    const unsigned long long rows = n >= BT_SLOTS ? ~0ull : ((1ull << (16 * n)) - 1ull);
+    const uint32_t off = me.g * (uint32_t)(GRAD_FLOATS * sizeof(float)) + L.slot_bytes;
+    if (__builtin_amdgcn_inverse_ballot_w64(L.m_out & rows))
+        asm volatile("global_atomic_add_f32 %0, %1, %2" ::"v"(off), "v"(m), "s"(L.grad_acc) : "memory");
+}
+
+template <bool POSE_ONLY>
+__global__ void __launch_bounds__(256) blend_backward_t_kernel(BlendArgs a, int ntiles,
+                                                               const float* __restrict__ final_T,
+                                                               const uint32_t* __restrict__ n_contrib,
+                                                               const float* __restrict__ dL_dcolor,
+                                                               const float* __restrict__ dL_ddepth,
+                                                               float* __restrict__ grad_acc) {
+    // [wave][factor h / w][slot][pixel]: 2 KB per wave
+    __shared__ __attribute__((aligned(16))) float s_fac[4][2][BT_SLOTS][WAVE];
+    __shared__ BtMetaRec s_meta[4][BT_SLOTS];                                            // [wave][slot] {cx, cy, index}
+    __shared__ __attribute__((aligned(16))) float s_pix[4][16][POSE_ONLY ? 4 : 16];      // [wave][q][(rgb,) depth x 4 pixels]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tile = (int)blockIdx.x;
+    if (tile >= ntiles) return;
+    const int tx = tile % a.gx, ty = tile / a.gx;
+    const uint2 range = a.ranges[tile];
+    if (range.y <= range.x) return;
+    const size_t HW = (size_t)a.H * a.W;
+    const float bg0 = a.bg[0], bg1 = a.bg[1], bg2 = a.bg[2];
+
+    // per-pixel state (lane = pixel of the 8x8 quadrant, as in blend_backward_kernel)
+    const int qx0i = tx * TILE + (wave & 1) * SUB, qy0i = ty * TILE + (wave >> 1) * SUB;
+    const int pxi = qx0i + (lane & 7), pyi = qy0i + (lane >> 3);
+    const bool inside = pxi < a.W && pyi < a.H;
+    const size_t pix = (size_t)pyi * a.W + pxi;
+    const float pxf = (float)pxi, pyf = (float)pyi, qx0 = (float)qx0i, qy0 = (float)qy0i;
+    const float T_final = inside ? final_T[pix] : 0.f;
+    const uint32_t last = inside ? n_contrib[pix] : 0u;
+    const float g0 = inside ? dL_dcolor[pix] : 0.f;
+    const float g1 = inside ? dL_dcolor[HW + pix] : 0.f;
+    const float g2 = inside ? dL_dcolor[2 * HW + pix] : 0.f;
+    const float gd = inside ? dL_ddepth[pix] : 0.f;
+    const float bgT = -T_final * (bg0 * g0 + bg1 * g1 + bg2 * g2);
+    float T = T_final, Bk = 0.f;
+    const uint32_t maxc = wave_max_u32(last);   // wave-uniform
+    if (maxc == 0) return;
+    const uint32_t end = range.x + maxc;
+
+    // the turned-round view: row = slot of the batch, lane q of the row = pixels 4q .. 4q+3 of the quadrant
+    const int q = lane & 15;
+    const int fxi = qx0i + 4 * (q & 1), fyi = qy0i + (q >> 1);
+    const float u0 = (float)fxi, v0 = (float)fyi;
+    // dL/dpixel of the lane's four pixels, constants of the launch, live in LDS, [q][channel][pixel] (pose-only: depth only)
+    // -- in registers they pushed the kernel past 64 VGPRs -- and come back with four (one) broadcast ds_read_b128 per batch:
+    // the four rows read the same addresses.
+    float* const fp = &s_pix[wave][q][0];
+    if (lane < 16) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool in_i = (fxi + i) < a.W && fyi < a.H;
+            const size_t px_i = (size_t)fyi * a.W + fxi + i;
+            if (!POSE_ONLY) {
+                fp[0 + i] = in_i ? dL_dcolor[px_i] : 0.f;
+                fp[4 + i] = in_i ? dL_dcolor[HW + px_i] : 0.f;
+                fp[8 + i] = in_i ? dL_dcolor[2 * HW + px_i] : 0.f;
+            }
+            fp[(POSE_ONLY ? 0 : 12) + i] = in_i ? dL_ddepth[px_i] : 0.f;
+        }
+    }
+    const int slot = POSE_ONLY ? bt_slot6(q) : bt_slot10(q);
+    const uint32_t slot_bytes = slot < 0 ? 0u : (uint32_t)slot * 4u;
+    const unsigned long long m_out = __builtin_amdgcn_ballot_w64(slot >= 0);            // lanes that carry a sum
+    const unsigned long long m_q0 = __builtin_amdgcn_ballot_w64((q & 3) == 0), m_q1 = __builtin_amdgcn_ballot_w64((q & 3) == 1);
+    float* const fh = &s_fac[wave][0][0][0];
+    float* const fw = &s_fac[wave][1][0][0];
+    BtMetaRec* const fmeta = &s_meta[wave][0];
+    const BtLane bl{fh, fw, fp, fmeta + (lane >> 4), lane, q, u0, v0, slot_bytes, m_out, m_q0, m_q1, grad_acc};
+    int k = 0;                      // survivors in the open batch (wave-uniform)
+
+    uint32_t gid_n = 0;
+    float4 box_n = make_float4(0.f, 0.f, -1.f, -1.f), ell_n = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto prefetch = [&](int b) {
+        gid_n = 0;
+        box_n = make_float4(0.f, 0.f, -1.f, -1.f);
+        const uint32_t i = range.x + (uint32_t)b * WAVE + lane;
+        if (b >= 0 && i < end) {
+            gid_n = a.point_list[i];
+            box_n = a.rec[(size_t)gid_n * 4];
+            ell_n = a.rec[(size_t)gid_n * 4 + 3];
+        }
+    };
+    prefetch((int)((maxc - 1) / WAVE));
+    for (int b = (int)((maxc - 1) / WAVE); b >= 0; --b) {
+        const uint32_t gid_l = gid_n;
+        const float4 c = box_n, el = ell_n;
+        prefetch(b - 1);
+        const unsigned long long alive = __builtin_amdgcn_ballot_w64(last >= (uint32_t)b * WAVE + 1u);
+        unsigned long long mask = __builtin_amdgcn_ballot_w64(quadrant_hit(c, el, qx0, qy0, alive));
+        const uint32_t k_first = (uint32_t)b * WAVE + 1u;          // 1-based list position of instance 0 of this step
+        while (mask) {
+            const int j = 63 - __builtin_clzll(mask);
+            mask &= ~(1ull << j);
+            const uint32_t gid = bcast(gid_l, j);
+            const Rec g = fetch(a, gid);
+            const float dx = g.px - pxf, dy = g.py - pyf;
+            const float power = dx * (g.ca * dx + g.cb * dy) + (g.cc * dy) * dy;
+            const float G = __builtin_amdgcn_exp2f(power);
+            const float alpha = fminf(0.99f, g.op * G);
+            const bool act = (k_first + (uint32_t)j <= last) && !(power > 0.f) && !(alpha < 1.0f / 255.0f);
+            if (__builtin_amdgcn_ballot_w64(act) == 0ull) continue;
+            const float a_eff = act ? alpha : 0.f;
+            const float inv = __builtin_amdgcn_rcpf(1.f - a_eff);
+            const float Tn = T * inv;
+            const float qq = POSE_ONLY ? __builtin_fmaf(g.z, gd, __builtin_fmaf(g.b, g2, __builtin_fmaf(g.g, g1, g.r * g0)))
+                                       : __builtin_fmaf(g.z, gd, __builtin_fmaf(g.b, g2, __builtin_fmaf(g.g, g1, g.r * g0)));
+            const float diff = qq - Bk;
+            const float dL_dalpha = diff * Tn + bgT * inv;
+            Bk = Bk + a_eff * diff;
+            T = Tn;
+            const float w = a_eff * Tn;
+            const float h = act ? G * dL_dalpha : 0.f;
+            // leave the two factors in the batch's slot (lane = pixel) and remember whose they are
+            // leave the two factors in slot k of the batch (lane = pixel).  Whose they are -- centre and index of the Gaussian --
+            // is noted by lane j, which has held all three in registers since it loaded instance j's cull box.
+            fh[k * WAVE + lane] = h;
+            fw[k * WAVE + lane] = w;
+            if (lane == j) fmeta[k] = BtMetaRec{c.x, c.y, gid_l};
+            if (++k == BT_SLOTS) {
+                bt_flush<POSE_ONLY>(bl, BT_SLOTS);
+                k = 0;
+            }
+        }
+    }
+    if (k) bt_flush<POSE_ONLY>(bl, k);
+}
+
 // ---- diagnostic: what the backward walk does, counted (not on the hot path; mgs_debug_blend_stats) --------------
 // The same walk, cull and per-pixel activity test as blend_backward_kernel<1, *>, with counters instead of gradient
 // arithmetic: stats[0] steps of 64 instances, [1] instances that pass the quadrant cull and are fetched ("survivors"),
@@ -480,13 +756,21 @@ int launch_blend_backward_stats(const mgs_camera& cam, const GeometryState& g, c
 
 // (The wave-per-tile and half-tile-per-wave variants of round 1 lost at every size and are gone; DESIGN.md section 4
 //  keeps their measurements.)
+int g_opt_blend_bwd_transposed = 1;     // mgs_debug_set_option("blend_bwd_transposed", 0 | 1): 0 = the per-survivor wave reduction
 int launch_blend_backward(const mgs_camera& cam, const GeometryState& g, const BinningState& b,
                           const ImageState& img, const float* dL_dcolor, const float* dL_ddepth, float* grad_acc,
                           bool pose_only, hipStream_t s) {
     const BlendArgs a = make_args(cam, g, b, img);
     const int ntiles = a.gx * tiles_y(a.H);
     if (ntiles == 0) return 0;
-    if (pose_only)
+    if (g_opt_blend_bwd_transposed != 0) {
+        if (pose_only)
+            hipLaunchKernelGGL((blend_backward_t_kernel<true>), dim3(ntiles), dim3(256), 0, s, a, ntiles, img.final_T,
+                               img.n_contrib, dL_dcolor, dL_ddepth, grad_acc);
+        else
+            hipLaunchKernelGGL((blend_backward_t_kernel<false>), dim3(ntiles), dim3(256), 0, s, a, ntiles, img.final_T,
+                               img.n_contrib, dL_dcolor, dL_ddepth, grad_acc);
+    } else if (pose_only)
         hipLaunchKernelGGL((blend_backward_kernel<true>), dim3(ntiles), dim3(256), 0, s, a, ntiles, img.final_T,
                            img.n_contrib, dL_dcolor, dL_ddepth, grad_acc);
     else

@@ -226,7 +226,7 @@ int launch_sort(const GeometryState& g, const BinningState& b, uint64_t R, int b
 int launch_ranges(const BinningState& b, uint64_t R, const ImageState& img, int ntiles, int sort_bits, hipStream_t s,
                   const uint32_t* n_dev = nullptr, uint32_t* status = nullptr);
 int set_radix_spin_limit(uint32_t limit);
-extern int g_opt_radix_scanned, g_opt_knn_grid_min, g_opt_scan_small, g_opt_dup_slot_major;      // test knobs (mgs_debug_set_option)
+extern int g_opt_radix_scanned, g_opt_knn_grid_min, g_opt_scan_small, g_opt_dup_slot_major, g_opt_blend_bwd_transposed;      // test knobs (mgs_debug_set_option)
 int launch_blend_forward(const mgs_camera& cam, const GeometryState& g, const BinningState& b,
                          const ImageState& img, float* out_color, float* out_depth, float* out_opacity,
                          int32_t* n_touched, hipStream_t s);

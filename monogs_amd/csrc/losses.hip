@@ -11,6 +11,8 @@
 //   tracking:  L = 0.5 * mean(opacity) * mean_{all 3HW} (m |rgb - gt|) + mean_{gt_depth > 0, opacity > 0.99} |depth - gt_depth|
 //              with m = mask * grad_mask * (opacity > 0.99); the depth term is 0 when its mask is empty
 //   rgb = exp(a) * render + b   (exposure; identity when `init`)
+//   invert_depth (slam_utils.py:83-88, :138-141): the depth term compares 1 / (depth + eps) with 1 / (gt_depth + eps),
+//   eps = 1e-6 in the tracking loss and 0 in the mapping loss, as the reference writes them
 //
 // Forward: one reduction kernel (<= 256 workgroups write partial sums) + a one-wave finalize kernel that adds
 // them in a fixed order (no atomics, no memset, bitwise reproducible); backward: one elementwise kernel.  HBM-bound: ~44 B/pixel read forward, ~60 B/pixel backward.
@@ -32,7 +34,7 @@ enum : int { LP_L1_RGB = 6, LP_L1_D = 7, LP_SCALE_RGB = 8, LP_SCALE_D = 9, LP_DA
 struct LossArgs {
     const float *render, *depth, *opacity, *gt_rgb, *gt_depth, *exp_a, *exp_b;
     const uint8_t *mask, *grad_mask;
-    int W, H, tracking, init;
+    int W, H, tracking, init, invert_depth;
     float lambda_rgb;
 };
 
@@ -58,7 +60,8 @@ __device__ __forceinline__ void fwd_pixel(const LossArgs& a, float ea, float eb,
         acc.u_b += s0 + s1 + s2;
     }
     if (m_d) {
-        acc.s_d += fabsf(d - gd);
+        const float eps = a.tracking ? 1e-6f : 0.f;
+        acc.s_d += a.invert_depth ? fabsf(1.f / (d + eps) - 1.f / (gd + eps)) : fabsf(d - gd);
         acc.c_d += 1.f;
     }
 }
@@ -218,7 +221,12 @@ __global__ void __launch_bounds__(LS_THREADS) loss_backward_kernel(LossArgs a, f
             const float s0 = sgn(ea * x0 + eb - t0), s1 = sgn(ea * x1 + eb - t1), s2 = sgn(ea * x2 + eb - t2);
             o0 = k_rgb * ea * s0; o1 = k_rgb * ea * s1; o2 = k_rgb * ea * s2;
         }
-        od = m_d ? k_d * sgn(d - gd) : 0.f;
+        if (a.invert_depth) {                       // d/dd |1/(d + eps) - 1/(gd + eps)| = -sgn(.) / (d + eps)^2
+            const float eps = a.tracking ? 1e-6f : 0.f, inv = 1.f / (d + eps);
+            od = m_d ? -k_d * sgn(inv - 1.f / (gd + eps)) * (inv * inv) : 0.f;
+        } else {
+            od = m_d ? k_d * sgn(d - gd) : 0.f;
+        }
     };
     if (VEC4) {
         const size_t NQ = HW / 4;
@@ -313,51 +321,55 @@ using namespace mgs;
 
 extern "C" {
 
-static int fill_args(LossArgs& a, int32_t W, int32_t H, int32_t tracking, int32_t init, float lambda_rgb,
+// `mode`: MGS_LOSS_TRACKING | MGS_LOSS_INVERT_DEPTH (0 = get_loss_mapping)
+static int fill_args(LossArgs& a, int32_t W, int32_t H, int32_t mode, int32_t init, float lambda_rgb,
                      const float* render, const float* depth, const float* opacity, const float* gt_rgb,
                      const float* gt_depth, const uint8_t* mask, const uint8_t* grad_mask, const float* exp_a,
                      const float* exp_b) {
     if (W <= 0 || H <= 0) { set_error("image size must be positive"); return 1; }
+    if (mode & ~(MGS_LOSS_TRACKING | MGS_LOSS_INVERT_DEPTH)) { set_error("unknown loss mode bits"); return 1; }
+    const int tracking = (mode & MGS_LOSS_TRACKING) ? 1 : 0;
     if (!render || !depth || !gt_rgb || !gt_depth) { set_error("render, depth, gt_rgb, gt_depth must be non-NULL"); return 1; }
     if (tracking && (!opacity || !grad_mask)) { set_error("tracking loss needs opacity and grad_mask"); return 1; }
     if (!init && (!exp_a || !exp_b)) { set_error("exposure_a / exposure_b must be non-NULL unless init"); return 1; }
     a.render = render; a.depth = depth; a.opacity = opacity; a.gt_rgb = gt_rgb; a.gt_depth = gt_depth;
     a.exp_a = exp_a; a.exp_b = exp_b; a.mask = mask; a.grad_mask = grad_mask;
     a.W = W; a.H = H; a.tracking = tracking; a.init = init; a.lambda_rgb = lambda_rgb;
+    a.invert_depth = (mode & MGS_LOSS_INVERT_DEPTH) ? 1 : 0;
     return 0;
 }
 
 size_t mgs_loss_scratch_bytes(void) { return (LP_N + LS_MAX_BLOCKS * LP_PART) * sizeof(float); }
 
-int mgs_loss_forward(int32_t W, int32_t H, int32_t tracking, int32_t init, float lambda_rgb, const float* render,
+int mgs_loss_forward(int32_t W, int32_t H, int32_t mode, int32_t init, float lambda_rgb, const float* render,
                      const float* depth, const float* opacity, const float* gt_rgb, const float* gt_depth,
                      const uint8_t* mask, const uint8_t* grad_mask, const float* exposure_a, const float* exposure_b,
                      float* scratch, float* loss_out, void* stream) {
     LossArgs a;
-    if (fill_args(a, W, H, tracking, init, lambda_rgb, render, depth, opacity, gt_rgb, gt_depth, mask, grad_mask,
+    if (fill_args(a, W, H, mode, init, lambda_rgb, render, depth, opacity, gt_rgb, gt_depth, mask, grad_mask,
                   exposure_a, exposure_b)) return 1;
     if (!scratch || !loss_out) { set_error("scratch and loss_out must be non-NULL"); return 1; }
     return launch_loss_forward(a, scratch, loss_out, (hipStream_t)stream);
 }
 
-int mgs_loss_backward(int32_t W, int32_t H, int32_t tracking, int32_t init, float lambda_rgb, const float* render,
+int mgs_loss_backward(int32_t W, int32_t H, int32_t mode, int32_t init, float lambda_rgb, const float* render,
                       const float* depth, const float* opacity, const float* gt_rgb, const float* gt_depth,
                       const uint8_t* mask, const uint8_t* grad_mask, const float* exposure_a, const float* exposure_b,
                       const float* scratch, const float* grad_out, float* d_render, float* d_depth, float* d_exposure,
                       void* stream) {
     LossArgs a;
-    if (fill_args(a, W, H, tracking, init, lambda_rgb, render, depth, opacity, gt_rgb, gt_depth, mask, grad_mask,
+    if (fill_args(a, W, H, mode, init, lambda_rgb, render, depth, opacity, gt_rgb, gt_depth, mask, grad_mask,
                   exposure_a, exposure_b)) return 1;
     if (!scratch || !d_render || !d_depth) { set_error("scratch, d_render, d_depth must be non-NULL"); return 1; }
     return launch_loss_backward(a, const_cast<float*>(scratch), grad_out, d_render, d_depth, d_exposure, (hipStream_t)stream);
 }
 
-int mgs_loss_grads(int32_t W, int32_t H, int32_t tracking, int32_t init, float lambda_rgb, const float* render,
+int mgs_loss_grads(int32_t W, int32_t H, int32_t mode, int32_t init, float lambda_rgb, const float* render,
                    const float* depth, const float* opacity, const float* gt_rgb, const float* gt_depth,
                    const uint8_t* mask, const uint8_t* grad_mask, const float* exposure_a, const float* exposure_b,
                    float* scratch, float* d_render, float* d_depth, void* stream) {
     LossArgs a;
-    if (fill_args(a, W, H, tracking, init, lambda_rgb, render, depth, opacity, gt_rgb, gt_depth, mask, grad_mask,
+    if (fill_args(a, W, H, mode, init, lambda_rgb, render, depth, opacity, gt_rgb, gt_depth, mask, grad_mask,
                   exposure_a, exposure_b)) return 1;
     if (!scratch || !d_render || !d_depth) { set_error("scratch, d_render, d_depth must be non-NULL"); return 1; }
     return launch_loss_grads(a, scratch, d_render, d_depth, (hipStream_t)stream);

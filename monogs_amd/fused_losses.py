@@ -3,9 +3,9 @@
 Same signatures and values as /root/reference/utils/slam_utils.py:58-146 (mirrored in plain PyTorch in
 ``oracle/slam_losses.py`` -- test infrastructure -- and checked there against the reference's own outputs); one reduction kernel
 per forward and one elementwise kernel per backward instead of ~60 small kernels and two host syncs.
-Differences, both invisible to the rasteriser: the opacity image receives no gradient from the tracking
-loss (the rasteriser ignores dL/dopacity anyway), and ``invert_depth`` is not supported (always False in
-the reference's callers).
+One difference, invisible to the rasteriser: the opacity image receives no gradient from the tracking loss (the
+rasteriser ignores dL/dopacity anyway).  ``invert_depth`` (slam_utils.py:83-88, :138-141) is the mode bit
+``MGS_LOSS_INVERT_DEPTH`` of the kernels.
 """
 from __future__ import annotations
 
@@ -15,7 +15,8 @@ from . import _lib
 from .rasterizer import _f32, _stream, _device_guard
 
 
-_DAB = 10     # MGS_LOSS_SCRATCH_DAB (include/monogs_raster.h)
+_TRACKING, _INVERT = 1, 2     # MGS_LOSS_TRACKING, MGS_LOSS_INVERT_DEPTH (include/monogs_raster.h)
+_DAB = 10     # MGS_LOSS_SCRATCH_DAB
 _LOSS = 12    # MGS_LOSS_SCRATCH_LOSS
 
 
@@ -29,7 +30,7 @@ def _u8(t):
 
 class _FusedLoss(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, render, depth, opacity, exp_a, exp_b, gt_rgb, gt_depth, mask, grad_mask, tracking, init, lam):
+    def forward(ctx, render, depth, opacity, exp_a, exp_b, gt_rgb, gt_depth, mask, grad_mask, mode, init, lam):
         lib = _lib.load()
         render = _f32(render.detach(), "render_image")
         depth = _f32(depth.detach(), "render_depth")
@@ -43,10 +44,10 @@ class _FusedLoss(torch.autograd.Function):
         with _device_guard(dev):
             scratch = torch.empty(lib.mgs_loss_scratch_bytes() // 4, dtype=torch.float32, device=dev)
             loss = torch.empty((), dtype=torch.float32, device=dev)
-            _lib.check(lib.mgs_loss_forward(W, H, int(tracking), int(init), float(lam), p(render), p(depth), p(opac),
+            _lib.check(lib.mgs_loss_forward(W, H, int(mode), int(init), float(lam), p(render), p(depth), p(opac),
                                             p(gt_rgb), p(gt_depth), p(mask), p(grad_mask), p(a), p(b),
                                             p(scratch), p(loss), _stream()), "mgs_loss_forward")
-        ctx.cfg = (W, H, int(tracking), int(init), float(lam))
+        ctx.cfg = (W, H, int(mode), int(init), float(lam))
         ctx.has_mask, ctx.has_gm, ctx.has_op, ctx.has_ab = mask is not None, grad_mask is not None, opac is not None, a is not None
         dummy = torch.empty(0, device=dev)
         ctx.save_for_backward(render, depth, opac if opac is not None else dummy, gt_rgb, gt_depth,
@@ -58,7 +59,7 @@ class _FusedLoss(torch.autograd.Function):
     def backward(ctx, grad_out):
         lib = _lib.load()
         render, depth, opac, gt_rgb, gt_depth, mask, gm, a, b, scratch = ctx.saved_tensors
-        W, H, tracking, init, lam = ctx.cfg
+        W, H, mode, init, lam = ctx.cfg
         dev = render.device
         p = lambda t, ok=True: t.data_ptr() if ok else None  # noqa: E731
         with _device_guard(dev):
@@ -73,7 +74,7 @@ class _FusedLoss(torch.autograd.Function):
                 else:                                      # the slot the forward left zeroed (MGS_LOSS_SCRATCH_DAB)
                     d_ab = scratch[_DAB:_DAB + 2]
                     ctx.dab_used = True
-            _lib.check(lib.mgs_loss_backward(W, H, tracking, init, lam, p(render), p(depth), p(opac, ctx.has_op),
+            _lib.check(lib.mgs_loss_backward(W, H, mode, init, lam, p(render), p(depth), p(opac, ctx.has_op),
                                              p(gt_rgb), p(gt_depth), p(mask, ctx.has_mask), p(gm, ctx.has_gm),
                                              p(a, ctx.has_ab), p(b, ctx.has_ab), p(scratch), p(go), p(d_render),
                                              p(d_depth), d_ab.data_ptr() if d_ab is not None else None, _stream()),
@@ -84,19 +85,15 @@ class _FusedLoss(torch.autograd.Function):
 
 
 def get_loss_mapping(render_image, render_depth, viewpoint, init=False, invert_depth=False, lambda_depth=0.9):
-    if invert_depth:
-        raise NotImplementedError("invert_depth is not supported by the fused loss (always False in the reference's callers)")
     return _FusedLoss.apply(render_image, render_depth, None, viewpoint.exposure_a, viewpoint.exposure_b,
-                            viewpoint.rgb, viewpoint.depth, _u8(viewpoint.mask), None, False, bool(init),
-                            float(lambda_depth))
+                            viewpoint.rgb, viewpoint.depth, _u8(viewpoint.mask), None,
+                            _INVERT if invert_depth else 0, bool(init), float(lambda_depth))
 
 
 def get_loss_tracking(render_image, render_depth, render_opacity, viewpoint, invert_depth=False, lambda_depth=0.9):
-    if invert_depth:
-        raise NotImplementedError("invert_depth is not supported by the fused loss (always False in the reference's callers)")
     return _FusedLoss.apply(render_image, render_depth, render_opacity, viewpoint.exposure_a, viewpoint.exposure_b,
-                            viewpoint.rgb, viewpoint.depth, _u8(viewpoint.mask), _u8(viewpoint.grad_mask), True,
-                            False, 0.9)
+                            viewpoint.rgb, viewpoint.depth, _u8(viewpoint.mask), _u8(viewpoint.grad_mask),
+                            _TRACKING | (_INVERT if invert_depth else 0), False, 0.9)
 
 
 class LossGrads:
@@ -128,7 +125,7 @@ class LossGrads:
 
 @torch.no_grad()
 def loss_grads(render_image, render_depth, render_opacity, viewpoint, tracking: bool, init: bool = False,
-               lambda_depth: float = 0.9) -> LossGrads:
+               lambda_depth: float = 0.9, invert_depth: bool = False) -> LossGrads:
     """``get_loss_tracking`` / ``get_loss_mapping`` (/root/reference/utils/slam_utils.py:58-146) as VALUE + GRADIENTS in two
     launches, for loops that call the rasteriser's backward themselves: no autograd node for the scalar, hence no finalize
     kernel, no ones-fill and no loss-summing adds (``loss.backward()`` on the fused autograd loss costs four launches per
@@ -148,7 +145,8 @@ def loss_grads(render_image, render_depth, render_opacity, viewpoint, tracking: 
     with _device_guard(dev):
         scratch = torch.empty(lib.mgs_loss_scratch_bytes() // 4, dtype=torch.float32, device=dev)
         d_render, d_depth = torch.empty_like(render), torch.empty_like(depth)
-        _lib.check(lib.mgs_loss_grads(W, H, int(tracking), int(init), 0.9 if tracking else float(lambda_depth), p(render),
+        mode = (_TRACKING if tracking else 0) | (_INVERT if invert_depth else 0)
+        _lib.check(lib.mgs_loss_grads(W, H, mode, int(init), 0.9 if tracking else float(lambda_depth), p(render),
                                       p(depth), p(opac), p(gt_rgb), p(gt_depth), p(mask), p(gm), p(a), p(b), p(scratch),
                                       p(d_render), p(d_depth), _stream()), "mgs_loss_grads")
     return LossGrads(d_render, d_depth, scratch, not init)

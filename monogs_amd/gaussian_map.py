@@ -188,10 +188,16 @@ class GaussianMap:
         self._opacity = self.optimizer.replace(2, new)
 
     @torch.no_grad()
-    def reset_opacity_nonvisible(self, visibility_filters):
+    def reset_opacity_nonvisible(self, visibility_filters, as_reference: bool = True):
+        """gaussian_model.py:527-535.  The reference writes the ACTIVATED opacity of the visible Gaussians into the raw
+        parameter (``opacities_new[filter] = self.get_opacity[filter]``), so a visible Gaussian comes out of the reset with
+        opacity sigmoid(sigmoid(x)) in [0.5, 0.73].  ``as_reference=True`` (default) reproduces that bit for bit -- a drop-in
+        must give the reference's map; ``as_reference=False`` keeps the visible Gaussians' raw opacity (what the upstream
+        MonoGS code base intends).  Pinned either way by tests/test_host_api.py."""
         new = inverse_sigmoid(torch.ones_like(self._opacity) * 0.4)
+        src = self.get_opacity.detach() if as_reference else self._opacity.detach()
         for f in visibility_filters:
-            new[f] = self._opacity.detach()[f]          # = inverse_sigmoid(get_opacity[f]) without the round trip
+            new[f] = src[f]
         self._opacity = self.optimizer.replace(2, new)
 
     def update_learning_rate(self, iteration: int):

@@ -30,9 +30,10 @@ class GaussianAdam:
     # What GaussianModel does to torch.optim.Adam's state when the map changes size
     # (/root/reference/gaussian_splatting/scene/gaussian_model.py:642-776): the moments of surviving Gaussians are
     # carried over exactly, new Gaussians start from zero moments, a replaced tensor restarts from zero moments.  The
-    # step count is untouched in all three cases (torch keeps ``state["step"]`` across the surgery as well), and it is
-    # ONE count for all tensors here -- identical to torch as long as every group steps together, which the mapper
-    # does (slam_mapper.py:482).  Each method returns the new leaf tensors (requires_grad) that replace ``params``.
+    # step count is untouched in all three cases (torch keeps ``state["step"]`` across the surgery as well); it is kept
+    # PER TENSOR on the device (``t_dev``), as torch keeps one per parameter -- a tensor whose gradient is None skips its
+    # step and its count, exactly like torch.  Each method returns the new leaf tensors (requires_grad) that replace
+    # ``params``.
     @torch.no_grad()
     def extend(self, new_tensors: Sequence[torch.Tensor]):
         """``cat_tensors_to_optimizer`` (gaussian_model.py:709-743): append rows, zero moments for them."""

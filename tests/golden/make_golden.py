@@ -8,6 +8,7 @@ Outputs (data only -- inputs and the reference's outputs):
   camera_pose.npz : getProjectionMatrix / getWorld2View / CameraIntrinsics.FoV / SE3_exp / update_pose
   sh_eval.npz     : eval_sh for degrees 0..3 on seeded inputs
   losses.npz      : get_loss_mapping / get_loss_tracking values and autograd gradients on seeded images
+  losses_invert.npz: the same with invert_depth=True
   lr_schedule.npz : general_utils.helper (the xyz learning-rate schedule of update_learning_rate)
   median_depth.npz: get_median_depth (value, std, valid mask) on a seeded depth image with holes, with and without a mask
 """
@@ -133,6 +134,35 @@ def losses():
     np.savez_compressed(os.path.join(HERE, "losses.npz"), **out)
 
 
+def losses_invert():
+    """The `invert_depth=True` branches (slam_utils.py:83-88 with eps = 1e-6, :138-141 without)."""
+    g = torch.Generator().manual_seed(17)
+    H, W = 24, 32
+    vp = types.SimpleNamespace()
+    vp.rgb = torch.rand(3, H, W, generator=g)
+    vp.depth = torch.rand(H, W, generator=g) * 3.0 + 0.3
+    vp.depth[torch.rand(H, W, generator=g) < 0.2] = 0.0
+    vp.mask = torch.rand(H, W, generator=g) > 0.1
+    vp.grad_mask = torch.rand(H, W, generator=g) > 0.4
+    vp.exposure_a = torch.tensor([0.05])
+    vp.exposure_b = torch.tensor([-0.02])
+    render = torch.rand(3, H, W, generator=g).requires_grad_(True)
+    depth = (torch.rand(1, H, W, generator=g) * 3.0 + 0.3).requires_grad_(True)
+    opacity = torch.rand(1, H, W, generator=g)
+    opacity[torch.rand(1, H, W, generator=g) < 0.6] = 0.995
+    out = {"gt_rgb": vp.rgb.numpy(), "gt_depth": vp.depth.numpy(), "gt_mask": vp.mask.numpy(),
+           "grad_mask": vp.grad_mask.numpy(), "opacity": opacity.numpy(),
+           "exposure": np.array([0.05, -0.02], dtype=np.float32),
+           "render": render.detach().numpy(), "depth": depth.detach().numpy()}
+    loss = get_loss_mapping(render, depth, vp, init=False, invert_depth=True)
+    gr, gd = torch.autograd.grad(loss, [render, depth])
+    out["loss_map"], out["grad_render_map"], out["grad_depth_map"] = np.array([loss.item()]), gr.numpy(), gd.numpy()
+    loss = get_loss_tracking(render, depth, opacity, vp, invert_depth=True)
+    gr, gd = torch.autograd.grad(loss, [render, depth])
+    out["loss_track"], out["grad_render_track"], out["grad_depth_track"] = np.array([loss.item()]), gr.numpy(), gd.numpy()
+    np.savez_compressed(os.path.join(HERE, "losses_invert.npz"), **out)
+
+
 def median_depth():
     g = torch.Generator().manual_seed(77)
     depth = torch.rand(1, 48, 64, generator=g) * 5.0
@@ -163,12 +193,13 @@ def lr_schedule():
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] in ("median_depth", "lr_schedule"):   # add one fixture without rewriting the others
-        {"median_depth": median_depth, "lr_schedule": lr_schedule}[sys.argv[1]]()
+    if len(sys.argv) > 1 and sys.argv[1] in ("median_depth", "lr_schedule", "losses_invert"):   # add one fixture without rewriting the others
+        {"median_depth": median_depth, "lr_schedule": lr_schedule, "losses_invert": losses_invert}[sys.argv[1]]()
         sys.exit(0)
     camera_pose()
     sh_eval()
     losses()
+    losses_invert()
     median_depth()
     lr_schedule()
     print("golden fixtures written to", HERE)

@@ -83,6 +83,29 @@ def test_fused_losses_against_reference_golden(native_lib):
     assert np.allclose(gd.cpu().numpy(), d["grad_depth_track"], atol=1e-8)
 
 
+def test_fused_losses_invert_depth_against_reference_golden(native_lib):
+    """`invert_depth=True` (/root/reference/utils/slam_utils.py:83-88, :138-141) against the reference's own outputs."""
+    from monogs_amd import fused_losses as F
+    d = np.load(os.path.join(G, "losses_invert.npz"))
+    t = lambda k: torch.tensor(d[k]).to(DEV)  # noqa: E731
+    vp = types.SimpleNamespace(rgb=t("gt_rgb"), depth=t("gt_depth"), mask=t("gt_mask"), grad_mask=t("grad_mask"),
+                               exposure_a=torch.tensor([float(d["exposure"][0])], device=DEV),
+                               exposure_b=torch.tensor([float(d["exposure"][1])], device=DEV))
+    render, depth = t("render").requires_grad_(True), t("depth").requires_grad_(True)
+    loss = F.get_loss_mapping(render, depth, vp, invert_depth=True)
+    gr, gd = torch.autograd.grad(loss, [render, depth])
+    assert abs(loss.item() - d["loss_map"][0]) < 2e-6
+    assert np.allclose(gr.cpu().numpy(), d["grad_render_map"], atol=1e-8)
+    assert np.allclose(gd.cpu().numpy(), d["grad_depth_map"], rtol=1e-5, atol=1e-8)
+    loss = F.get_loss_tracking(render, depth, t("opacity"), vp, invert_depth=True)
+    gr, gd = torch.autograd.grad(loss, [render, depth])
+    assert abs(loss.item() - d["loss_track"][0]) < 2e-6
+    assert np.allclose(gr.cpu().numpy(), d["grad_render_track"], atol=1e-8)
+    assert np.allclose(gd.cpu().numpy(), d["grad_depth_track"], rtol=1e-5, atol=1e-8)
+    lg = F.loss_grads(render, depth, None, vp, tracking=False, invert_depth=True)       # the two-launch path
+    assert np.allclose(lg.d_depth.cpu().numpy(), d["grad_depth_map"], rtol=1e-5, atol=1e-8)
+
+
 @pytest.mark.parametrize("tracking,init", [(True, False), (False, False), (False, True)])
 @pytest.mark.parametrize("H,W", [(480, 640), (237, 325)])
 def test_loss_grads_two_launch_path_equals_the_autograd_loss(native_lib, tracking, init, H, W):
@@ -101,6 +124,6 @@ def test_loss_grads_two_launch_path_equals_the_autograd_loss(native_lib, trackin
     assert torch.equal(lg.d_render, ref[0]) and torch.equal(lg.d_depth, ref[1])
     if init:
         assert lg.d_exposure_a is None
-    else:           # block-level float atomics: summation order varies
+    else:           # (scale x the forward's unscaled sums, stored by one thread: rounding differs from autograd's order)
         assert torch.allclose(lg.d_exposure_a, ref[2], rtol=1e-5, atol=1e-9)
         assert torch.allclose(lg.d_exposure_b, ref[3], rtol=1e-5, atol=1e-9)

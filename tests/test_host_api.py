@@ -61,3 +61,28 @@ def test_synthetic_scene_is_deterministic():
             assert torch.equal(x, y)
     c = make_scene(500, "fr3_office", seed=4)
     assert not torch.equal(a.means3D, c.means3D)
+
+
+def test_reset_opacity_nonvisible_as_the_reference():
+    """/root/reference/gaussian_splatting/scene/gaussian_model.py:527-535, restated line by line: the new raw opacity is
+    inverse_sigmoid(0.4) everywhere, then ``opacities_new[filter] = self.get_opacity[filter]`` for every visibility
+    filter -- the ACTIVATED value goes into the raw parameter -- and the Adam moments of the tensor restart from zero
+    (``replace_tensor_to_optimizer``, :642-656).  ``as_reference=False`` keeps the raw value of the visible ones."""
+    from monogs_amd.gaussian_map import GaussianMap, inverse_sigmoid
+    g = torch.Generator().manual_seed(5)
+    P = 40
+    raw = torch.randn(P, 1, generator=g)
+    filters = [torch.rand(P, generator=g) > 0.6, torch.rand(P, generator=g) > 0.7]
+    for as_ref in (True, False):
+        m = GaussianMap("cpu")
+        m.densification_postfix(torch.randn(P, 3, generator=g), torch.rand(P, 3, generator=g), raw.clone(),
+                                torch.randn(P, 1, generator=g), torch.randn(P, 4, generator=g))
+        m.optimizer.exp_avg[2].fill_(0.3)
+        m.optimizer.exp_avg_sq[2].fill_(0.2)
+        expected = inverse_sigmoid(torch.ones(P, 1) * 0.4)
+        for f in filters:
+            expected[f] = (torch.sigmoid(raw) if as_ref else raw)[f]
+        m.reset_opacity_nonvisible(filters, as_reference=as_ref)
+        assert torch.equal(m._opacity.detach(), expected) and m._opacity.requires_grad
+        assert m.optimizer.params[2] is m._opacity
+        assert float(m.optimizer.exp_avg[2].abs().max()) == 0.0 and float(m.optimizer.exp_avg_sq[2].abs().max()) == 0.0

@@ -10,7 +10,7 @@ A="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACT
 B="SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INSTS_SMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VMEM SQ_WAVES"
 for p in a b; do
   if [ $p = a ]; then C="$A"; else C="$B"; fi
-  rm -rf /tmp/pmc_$tag_$p
+  rm -rf /tmp/pmc_${tag}_$p
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/pmc_${tag}_$p -o c -- python3 $R/bench.py --no-cpu-baseline --no-slam --steps 3 --warmup 1 > /tmp/pmc_${tag}_$p.log 2>&1
   f=$(find /tmp/pmc_${tag}_$p -name '*counter_collection.csv' | head -1)
   python3 $R/tools/pmc_table.py $f ${PMC_FILTER:-blend} > $R/gpurun_out/pmc_${tag}_$p.txt 2>&1 || tail -5 /tmp/pmc_${tag}_$p.log

@@ -1,37 +1,191 @@
-// Micro-benchmark: issue rate of v_fma_f32 vs v_pk_fma_f32 vs v_exp_f32 vs DPP add vs permlane swap on gfx950,
-// 8 waves per SIMD, every CU busy.  Prints wave-instructions per SIMD-cycle (assuming 2.4 GHz is NOT assumed:
-// reports ns per instruction per SIMD and the ratio between variants).
+// Micro-benchmark: issue cost of the instructions the blend kernels are built from, on gfx950, 8 waves per SIMD, every CU
+// busy.  Reports ns per wave-instruction per SIMD (no clock assumed) and "cycles" at the nominal 2.4 GHz; under this
+// load the chip does not hold 2.4 GHz, so read the plain v_fma_f32 row as "2 cycles" (MI355X_MICROARCH.md: wave64
+// v_fma_f32 issues in 2 cycles on the SIMD-32) and every other row relative to it.
+//
+//   hipcc --offload-arch=gfx950 -O3 valu_rate.hip -o valu_rate && ./valu_rate
+//
+// Rows "seq: ..." time whole reduction sequences of the blend backward (10 per-lane values -> 10 wave sums) the way the
+// kernel runs them, so that a restructuring can be priced before it is built.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef float float2_ __attribute__((ext_vector_type(2)));
 
+#define R8(M) M(a0) M(a1) M(a2) M(a3) M(a4) M(a5) M(a6) M(a7)
+
+__device__ __forceinline__ float swap32_add(float x, float y) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float swap16_add(float x, float y) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+template <int XOR>
+__device__ __forceinline__ float swz_add(float v) {
+    return v + __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x001F | (XOR << 10)));
+}
+__device__ __forceinline__ float row_sum_all(float v) {
+    v = swz_add<1>(v); v = swz_add<2>(v); v = swz_add<4>(v); v = swz_add<8>(v);
+    return v;
+}
+// the reduction of blend_backward_kernel<false> as of round 2 (7 swaps, 20 adds, 13 swizzles, 2 selects)
+__device__ __forceinline__ float reduce10_r2(float a0, float a1, float a2, float a3, float a4, float a5, float a6,
+                                             float a7, float a8, float a9, int lane) {
+    const float b0 = swap32_add(a0, a1), b1 = swap32_add(a2, a3), b2 = swap32_add(a4, a5);
+    const float b3 = swap32_add(a6, a7), b4 = swap32_add(a8, a9);
+    float c0 = swap16_add(b0, b1), c1 = swap16_add(b2, b3), c2 = swz_add<16>(b4);
+    c0 = row_sum_all(c0); c1 = row_sum_all(c1); c2 = row_sum_all(c2);
+    const int pos = lane & 15;
+    return pos == 15 ? c0 : (pos == 0 ? c1 : c2);
+}
+// x/y-separable variant: lane = 8 x + y.  Seven values {h, h dx, h dx^2, wr, wg, wb, wz} (+ h again) are summed over x with
+// the packing swaps (x = lane bits 5..3), the three y-weighted copies are formed on the row sums, then ONE 3-stage
+// butterfly over y on two registers: 6 swaps, 14 adds, 8 swizzles, 2 muls, 3 selects.
+__device__ __forceinline__ float reduce_sep(float h, float hx, float hxx, float wr, float wg, float wb, float wz,
+                                            float dy, unsigned long long m_dy, unsigned long long m_dy2,
+                                            unsigned long long m_sel) {
+    const float b0 = swap32_add(h, hx), b1 = swap32_add(hxx, wr), b2 = swap32_add(wg, wb), b3 = swap32_add(wz, h);
+    float c0 = swap16_add(b0, b1);     // rows: h hxx hx wr
+    float c1 = swap16_add(b2, b3);     // rows: wg wz wb h
+    c0 = swz_add<8>(c0);
+    c1 = swz_add<8>(c1);
+    const float c0y = c0 * dy, c1y = c1 * (dy * dy);
+    c0 = __builtin_amdgcn_inverse_ballot_w64(m_dy) ? c0y : c0;
+    c1 = __builtin_amdgcn_inverse_ballot_w64(m_dy2) ? c1y : c1;
+    c0 = swz_add<1>(c0); c0 = swz_add<2>(c0); c0 = swz_add<4>(c0);
+    c1 = swz_add<1>(c1); c1 = swz_add<2>(c1); c1 = swz_add<4>(c1);
+    return __builtin_amdgcn_inverse_ballot_w64(m_sel) ? c1 : c0;
+}
+
+enum {
+    M_FMA, M_PKFMA, M_EXP, M_RCP, M_DPP_SHR, M_DPP_QUAD, M_DPP_MOV, M_SWAP32, M_SWAP16, M_CMP_CND, M_CNDMASK, M_READLANE,
+    M_SWZ_ADD, M_BPERM_ADD, M_SWZ_ONLY, M_CND_SALU, M_CND_VCC1, M_CMPX, M_WRITELANE, M_DPP_BANK, M_MOV, M_CND_E64_INV, M_CND_VCC_MIX, M_SEQ_R2, M_SEQ_SEP, M_COUNT
+};
+static const char* names[M_COUNT] = {
+    "v_fma_f32", "v_pk_fma_f32", "v_exp_f32", "v_rcp_f32", "v_add_f32_dpp row_shr:1", "v_add_f32_dpp quad_perm",
+    "v_mov_b32_dpp row_shr:1", "v_permlane32_swap", "v_permlane16_swap", "v_cmp+v_cndmask (pair)",
+    "v_cndmask (SGPR mask)", "v_readlane+v_add (pair)", "ds_swizzle+v_add (pair)", "ds_bpermute+v_add (pair)",
+    "ds_swizzle chain (LDS pipe)", "v_cndmask, mask rewritten by SALU", "v_cndmask x8 after ONE v_cmp", "v_cmpx + 7 plain under EXEC",
+    "v_writelane (SGPR lane sel)", "v_add_f32_dpp row_ror:8 bank_mask", "v_mov_b32", "v_cndmask_e64 x8, SGPR mask invariant", "v_cndmask_e32 vcc + v_fma alternating (pair)", "seq: reduce10 round 2", "seq: reduce x/y-separable"};
+// wave-instructions of the row's kind per loop trip per wave (what the ns figure is divided by)
+static const double per_trip[M_COUNT] = {8, 8, 8, 8, 8, 8, 8, 8, 8, 16, 8, 16, 16, 16, 8, 8, 9, 8, 8, 8, 8, 8, 16, 1, 1};
+
 template <int MODE>
-__global__ void __launch_bounds__(256) k(float* out, int iters, float seed) {
+__global__ void __launch_bounds__(256) k(float* out, int iters, float seed, unsigned long long mask) {
     float a0 = seed + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
     float2_ p0 = {a0, a1}, p1 = {a2, a3}, p2 = {a4, a5}, p3 = {a6, a7}, p4 = {a1, a2}, p5 = {a3, a4}, p6 = {a5, a6}, p7 = {a7, a0};
     const float c = 1.0001f, d = 0.0001f;
     const float2_ c2 = {c, c}, d2 = {d, d};
+    const int lane = threadIdx.x & 63;
+    const int bp = (lane ^ 32) * 4;
+    const float src_never_written = seed * 3.f + lane;
     for (int i = 0; i < iters; ++i) {
-        if (MODE == 0) {
-            a0 = __builtin_fmaf(a0, c, d); a1 = __builtin_fmaf(a1, c, d); a2 = __builtin_fmaf(a2, c, d); a3 = __builtin_fmaf(a3, c, d);
-            a4 = __builtin_fmaf(a4, c, d); a5 = __builtin_fmaf(a5, c, d); a6 = __builtin_fmaf(a6, c, d); a7 = __builtin_fmaf(a7, c, d);
-        } else if (MODE == 1) {
+        if (MODE == M_FMA) {
+#define F(x) x = __builtin_fmaf(x, c, d);
+            R8(F)
+#undef F
+        } else if (MODE == M_PKFMA) {
             p0 = __builtin_elementwise_fma(p0, c2, d2); p1 = __builtin_elementwise_fma(p1, c2, d2);
             p2 = __builtin_elementwise_fma(p2, c2, d2); p3 = __builtin_elementwise_fma(p3, c2, d2);
             p4 = __builtin_elementwise_fma(p4, c2, d2); p5 = __builtin_elementwise_fma(p5, c2, d2);
             p6 = __builtin_elementwise_fma(p6, c2, d2); p7 = __builtin_elementwise_fma(p7, c2, d2);
-        } else if (MODE == 2) {
-            a0 = __builtin_amdgcn_exp2f(a0); a1 = __builtin_amdgcn_exp2f(a1); a2 = __builtin_amdgcn_exp2f(a2); a3 = __builtin_amdgcn_exp2f(a3);
-            a4 = __builtin_amdgcn_exp2f(a4); a5 = __builtin_amdgcn_exp2f(a5); a6 = __builtin_amdgcn_exp2f(a6); a7 = __builtin_amdgcn_exp2f(a7);
-        } else if (MODE == 3) {
-            #define DPP(x) x = x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x111, 0xf, 0xf, true))
-            DPP(a0); DPP(a1); DPP(a2); DPP(a3); DPP(a4); DPP(a5); DPP(a6); DPP(a7);
-        } else if (MODE == 4) {
-            #define SW(x, y) { auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false); x = __uint_as_float(r[0]); y = __uint_as_float(r[1]); }
-            SW(a0, a1); SW(a2, a3); SW(a4, a5); SW(a6, a7); SW(a0, a2); SW(a1, a3); SW(a4, a6); SW(a5, a7);
-        } else if (MODE == 5) {
+        } else if (MODE == M_EXP) {
+#define F(x) x = __builtin_amdgcn_exp2f(x);
+            R8(F)
+#undef F
+        } else if (MODE == M_RCP) {
+#define F(x) x = __builtin_amdgcn_rcpf(x);
+            R8(F)
+#undef F
+        } else if (MODE == M_DPP_SHR) {
+#define F(x) x = x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x111, 0xf, 0xf, true));
+            R8(F)
+#undef F
+        } else if (MODE == M_DPP_QUAD) {
+#define F(x) x = x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xf, 0xf, true));   /* quad_perm:[1,0,3,2] */
+            R8(F)
+#undef F
+        } else if (MODE == M_DPP_MOV) {
+#define F(x) x = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x111, 0xf, 0xf, true));
+            R8(F)
+#undef F
+        } else if (MODE == M_SWAP32) {
+#define SW(x, y) { auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false); x = __uint_as_float(r[0]); y = __uint_as_float(r[1]); }
+            SW(a0, a1) SW(a2, a3) SW(a4, a5) SW(a6, a7) SW(a0, a2) SW(a1, a3) SW(a4, a6) SW(a5, a7)
+#undef SW
+        } else if (MODE == M_SWAP16) {
+#define SW(x, y) { auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false); x = __uint_as_float(r[0]); y = __uint_as_float(r[1]); }
+            SW(a0, a1) SW(a2, a3) SW(a4, a5) SW(a6, a7) SW(a0, a2) SW(a1, a3) SW(a4, a6) SW(a5, a7)
+#undef SW
+        } else if (MODE == M_CMP_CND) {
             a0 = a0 > c ? a1 : a0; a1 = a1 > c ? a2 : a1; a2 = a2 > c ? a3 : a2; a3 = a3 > c ? a4 : a3;
             a4 = a4 > c ? a5 : a4; a5 = a5 > c ? a6 : a5; a6 = a6 > c ? a7 : a6; a7 = a7 > c ? a0 : a7;
+        } else if (MODE == M_CNDMASK) {
+            const bool s = __builtin_amdgcn_inverse_ballot_w64(mask);
+            a0 = s ? a1 : a0; a1 = s ? a2 : a1; a2 = s ? a3 : a2; a3 = s ? a4 : a3;
+            a4 = s ? a5 : a4; a5 = s ? a6 : a5; a6 = s ? a7 : a6; a7 = s ? a0 : a7;
+        } else if (MODE == M_READLANE) {
+#define F(x) x = x + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 5));
+            R8(F)
+#undef F
+        } else if (MODE == M_SWZ_ADD) {
+#define F(x) x = swz_add<1>(x);
+            R8(F)
+#undef F
+        } else if (MODE == M_BPERM_ADD) {
+#define F(x) x = x + __int_as_float(__builtin_amdgcn_ds_bpermute(bp, __float_as_int(x)));
+            R8(F)
+#undef F
+        } else if (MODE == M_SWZ_ONLY) {
+#define F(x) x = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(x), 0x001F | (1 << 10)));
+            R8(F)
+#undef F
+        } else if (MODE == M_CND_SALU) {
+            asm volatile("s_xor_b64 %0, %0, 0x55" : "+s"(mask));          // the mask is (re)written by the scalar unit every trip
+            const bool s = __builtin_amdgcn_inverse_ballot_w64(mask);
+            a0 = s ? a1 : a0; a1 = s ? a2 : a1; a2 = s ? a3 : a2; a3 = s ? a4 : a3;
+            a4 = s ? a5 : a4; a5 = s ? a6 : a5; a6 = s ? a7 : a6; a7 = s ? a0 : a7;
+        } else if (MODE == M_CND_VCC1) {
+            const bool s = a0 > c;                                           // ONE v_cmp (VALU writes the mask), eight selects on it
+            a0 = s ? a1 : a0; a1 = s ? a2 : a1; a2 = s ? a3 : a2; a3 = s ? a4 : a3;
+            a4 = s ? a5 : a4; a5 = s ? a6 : a5; a6 = s ? a7 : a6; a7 = s ? a0 : a7;
+        } else if (MODE == M_CMPX) {
+            if (a0 > c) {                                                    // v_cmpx / s_and_saveexec, then plain work under the narrowed EXEC
+                a1 = __builtin_fmaf(a1, c, d); a2 = __builtin_fmaf(a2, c, d); a3 = __builtin_fmaf(a3, c, d); a4 = __builtin_fmaf(a4, c, d);
+                a5 = __builtin_fmaf(a5, c, d); a6 = __builtin_fmaf(a6, c, d); a7 = __builtin_fmaf(a7, c, d);
+            }
+            a0 += d;
+        } else if (MODE == M_WRITELANE) {
+            const int sl = (i * 16) & 63;
+#define F(x) asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(x) : "s"(i), "s"(sl) : "m0");
+            R8(F)
+#undef F
+        } else if (MODE == M_DPP_BANK) {
+            // packing DPP add: only the lanes of banks 2, 3 (lane bit 3 set) are written, the others keep their value -- two of
+            // these with complementary bank masks halve two values into one register.  (Sources never written in this loop.)
+#define F(r) asm volatile("v_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xc" : "+v"(r) : "v"(src_never_written));
+            R8(F)
+#undef F
+        } else if (MODE == M_MOV) {
+#define F(x) asm volatile("v_mov_b32 %0, %1" : "=v"(x) : "v"(a0));
+            F(a1) F(a2) F(a3) F(a4) F(a5) F(a6) F(a7) F(p0.x)
+#undef F
+        } else if (MODE == M_CND_E64_INV) {
+#define F(r) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(r) : "v"(src_never_written), "s"(mask));
+            R8(F)
+#undef F
+        } else if (MODE == M_CND_VCC_MIX) {
+#define F(r) asm volatile("v_cndmask_b32_e32 %0, %0, %1, vcc\n\tv_fma_f32 %0, %0, %0, %1" : "+v"(r) : "v"(src_never_written));
+            asm volatile("s_mov_b64 vcc, %0" :: "s"(mask) : "vcc");
+            R8(F)
+#undef F
+        } else if (MODE == M_SEQ_R2) {
+            const float m = reduce10_r2(a0, a1, a2, a3, a4, a5, a6, a7, a0 + c, a1 + c, lane);
+            a0 += m; a1 -= m; a2 += d; a3 += d; a4 += d; a5 += d; a6 += d; a7 += d;     // 8 plain ops of "other work"
+        } else if (MODE == M_SEQ_SEP) {
+            const float m = reduce_sep(a0, a1, a2, a3, a4, a5, a6, a7, mask, mask >> 7, mask >> 13);
+            a0 += m; a1 -= m; a2 += d; a3 += d; a4 += d; a5 += d; a6 += d; a7 += d;
         }
     }
     out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + p0.x + p0.y + p1.x + p1.y + p2.x + p2.y + p3.x + p3.y +
@@ -43,25 +197,34 @@ float run(float* out, int iters) {
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     const int blocks = 256 * 8;   // 8 blocks of 4 waves per CU = 8 waves per SIMD
-    hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, out, 10, 1.0f);
+    hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, out, 10, 1.0f, 0x00FF00FF00FF00FFull);
     hipEventRecord(e0);
-    hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, out, iters, 1.0f);
+    hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, out, iters, 1.0f, 0x00FF00FF00FF00FFull);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     return ms;
 }
 
+template <int M>
+void all(float* out, int iters, float* ms) {
+    ms[M] = run<M>(out, iters);
+    if constexpr (M + 1 < M_COUNT) all<M + 1>(out, iters, ms);
+}
+
 int main() {
     float* out; hipMalloc(&out, 256 * 8 * 256 * 4);
     const int iters = 20000;
-    const char* names[] = {"v_fma_f32", "v_pk_fma_f32", "v_exp_f32", "v_add_f32_dpp", "v_permlane32_swap", "v_cmp+v_cndmask"};
-    float ms[6] = {run<0>(out, iters), run<1>(out, iters), run<2>(out, iters), run<3>(out, iters), run<4>(out, iters), run<5>(out, iters)};
-    for (int m = 0; m < 6; ++m) {
-        // per SIMD: 8 waves x iters x 8 instr (x2 for mode 5)
-        const double instr = 8.0 * iters * 8 * (m == 5 ? 2 : 1);
-        printf("%-20s %8.3f ms  -> %.2f ns per wave-instruction per SIMD (%.2f cycles @2.4GHz)\n", names[m], ms[m],
-               ms[m] * 1e6 / instr, ms[m] * 1e6 / instr * 2.4);
+    float ms[M_COUNT];
+    all<0>(out, iters, ms);
+    const double fma_ns = ms[M_FMA] * 1e6 / (8.0 * iters * per_trip[M_FMA]);
+    printf("%-32s %9s  %s\n", "instruction", "ms", "ns per wave-instruction per SIMD (cycles @2.4 GHz; x plain v_fma_f32)");
+    for (int m = 0; m < M_COUNT; ++m) {
+        const double ns = ms[m] * 1e6 / (8.0 * iters * per_trip[m]);   // 8 waves per SIMD
+        printf("%-32s %9.3f  %7.2f ns  (%6.2f cycles; %5.2f x fma)%s\n", names[m], ms[m], ns, ns * 2.4, ns / fma_ns,
+               m >= M_SEQ_R2 ? "  [whole sequence + 8 plain ops]" : "");
     }
+    printf("chip-wide plain-FMA issue ceiling measured here: %.1f G wave-inst/s (spec: 1024 SIMDs x 2.4 GHz / 2 = 1228.8)\n",
+           1024.0 / fma_ns);
     return 0;
 }

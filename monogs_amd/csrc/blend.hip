@@ -509,22 +509,30 @@ __device__ __forceinline__ float reduce_rows6(float v0, float v1, float v2, floa
 struct __attribute__((aligned(16))) BtMetaRec { float x, y; uint32_t g; };
 // What a lane needs to turn a batch round (all by value: a by-reference lambda ended up as a closure object in scratch).
 struct BtLane {
-    const float *fh, *fw, *fp;      // this wave's factor slabs; this lane's dL/dpixel block [rgb, depth][4 pixels] (LDS)
-    const BtMetaRec* fm;            // the metadata {centre x, centre y, Gaussian index} of this lane's row (LDS)
-    int lane, q;
-    float u0, v0;
+    const float* fac;               // this wave's factor slab [h | w][slot][pixel] (LDS)
+    const float* pix;               // this wave's dL/dpixel block [q][(rgb,) depth x 4 pixels] (LDS)
+    const BtMetaRec* meta;          // this wave's metadata [slot] {centre x, centre y, Gaussian index} (LDS)
+    int lane;
+    float qx0, qy0;                 // first pixel of the quadrant (wave-uniform)
     uint32_t slot_bytes;
     unsigned long long m_out, m_q0, m_q1;
     float* grad_acc;
 };
 template <bool POSE_ONLY>
 __device__ __forceinline__ void bt_flush(const BtLane L, int n) {
-    const int lane = L.lane, q = L.q;
-    const float4 h4 = *reinterpret_cast<const float4*>(L.fh + (lane >> 4) * WAVE + 4 * q);
-    const float4 w4 = *reinterpret_cast<const float4*>(L.fw + (lane >> 4) * WAVE + 4 * q);
-    const BtMetaRec me = *L.fm;
-    const float dy = me.y - L.v0;
-    const float dx0 = me.x - L.u0, dx1 = dx0 - 1.f, dx2 = dx0 - 2.f, dx3 = dx0 - 3.f;
+    // Everything a lane derives from its number here (row, q, three LDS addresses, its first pixel) is RE-derived per batch,
+    // ~8 VALU per four survivors: hoisted out of the walk by the compiler these values cost six more VGPRs over the whole
+    // kernel, i.e. a wave per SIMD.  The empty asm keeps the loop-invariant code motion from undoing that.
+    int lane = L.lane;
+    asm volatile("" : "+v"(lane));
+    const int q = lane & 15, row = lane >> 4;
+    const float4 h4 = *reinterpret_cast<const float4*>(L.fac + 4 * lane);                   // [row][4 q .. 4 q + 3]
+    const float4 w4 = *reinterpret_cast<const float4*>(L.fac + BT_SLOTS * WAVE + 4 * lane);
+    const BtMetaRec me = L.meta[row];
+    const float* const fp = L.pix + q * (POSE_ONLY ? 4 : 16);
+    const float u0 = L.qx0 + (float)(4 * (q & 1)), v0 = L.qy0 + (float)(q >> 1);
+    const float dy = me.y - v0;
+    const float dx0 = me.x - u0, dx1 = dx0 - 1.f, dx2 = dx0 - 2.f, dx3 = dx0 - 3.f;
     const float hx0 = h4.x * dx0, hx1 = h4.y * dx1, hx2 = h4.z * dx2, hx3 = h4.w * dx3;
     const float H0 = (h4.x + h4.y) + (h4.z + h4.w);
     const float H1 = (hx0 + hx1) + (hx2 + hx3);
@@ -532,12 +540,12 @@ __device__ __forceinline__ void bt_flush(const BtLane L, int n) {
     const float s_y = dy * H0, s_xy = dy * H1, s_yy = dy * s_y;
     float m;
     if (POSE_ONLY) {
-        const float4 c3 = *reinterpret_cast<const float4*>(L.fp);
+        const float4 c3 = *reinterpret_cast<const float4*>(fp);
         const float s_z = __builtin_fmaf(w4.w, c3.w, __builtin_fmaf(w4.z, c3.z, __builtin_fmaf(w4.y, c3.y, w4.x * c3.x)));
         m = reduce_rows6(H1, s_y, H2, s_xy, s_yy, s_z, L.m_q0);
     } else {
-        const float4 c0 = *reinterpret_cast<const float4*>(L.fp), c1 = *reinterpret_cast<const float4*>(L.fp + 4),
-                     c2 = *reinterpret_cast<const float4*>(L.fp + 8), c3 = *reinterpret_cast<const float4*>(L.fp + 12);
+        const float4 c0 = *reinterpret_cast<const float4*>(fp), c1 = *reinterpret_cast<const float4*>(fp + 4),
+                     c2 = *reinterpret_cast<const float4*>(fp + 8), c3 = *reinterpret_cast<const float4*>(fp + 12);
         const float s_r = __builtin_fmaf(w4.w, c0.w, __builtin_fmaf(w4.z, c0.z, __builtin_fmaf(w4.y, c0.y, w4.x * c0.x)));
         const float s_g = __builtin_fmaf(w4.w, c1.w, __builtin_fmaf(w4.z, c1.z, __builtin_fmaf(w4.y, c1.y, w4.x * c1.x)));
         const float s_b = __builtin_fmaf(w4.w, c2.w, __builtin_fmaf(w4.z, c2.z, __builtin_fmaf(w4.y, c2.y, w4.x * c2.x)));
@@ -562,7 +570,9 @@ __global__ void __launch_bounds__(256) blend_backward_t_kernel(BlendArgs a, int 
     __shared__ __attribute__((aligned(16))) float s_fac[4][2][BT_SLOTS][WAVE];
     __shared__ BtMetaRec s_meta[4][BT_SLOTS];                                            // [wave][slot] {cx, cy, index}
     __shared__ __attribute__((aligned(16))) float s_pix[4][16][POSE_ONLY ? 4 : 16];      // [wave][q][(rgb,) depth x 4 pixels]
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // (the wave number is wave-uniform but computed from a per-lane register: readfirstlane tells the compiler, and the
+    //  quadrant origin and the LDS bases derived from it then live in SGPRs -- five VGPRs less)
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int tile = (int)blockIdx.x;
     if (tile >= ntiles) return;
     const int tx = tile % a.gx, ty = tile / a.gx;
@@ -585,14 +595,13 @@ __global__ void __launch_bounds__(256) blend_backward_t_kernel(BlendArgs a, int 
     const float gd = inside ? dL_ddepth[pix] : 0.f;
     const float bgT = -T_final * (bg0 * g0 + bg1 * g1 + bg2 * g2);
     float T = T_final, Bk = 0.f;
-    const uint32_t maxc = wave_max_u32(last);   // wave-uniform
+    const uint32_t maxc = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max_u32(last));   // wave-uniform, in an SGPR
     if (maxc == 0) return;
     const uint32_t end = range.x + maxc;
 
     // the turned-round view: row = slot of the batch, lane q of the row = pixels 4q .. 4q+3 of the quadrant
     const int q = lane & 15;
     const int fxi = qx0i + 4 * (q & 1), fyi = qy0i + (q >> 1);
-    const float u0 = (float)fxi, v0 = (float)fyi;
     // dL/dpixel of the lane's four pixels, constants of the launch, live in LDS, [q][channel][pixel] (pose-only: depth only)
     // -- in registers they pushed the kernel past 64 VGPRs -- and come back with four (one) broadcast ds_read_b128 per batch:
     // the four rows read the same addresses.
@@ -614,10 +623,9 @@ __global__ void __launch_bounds__(256) blend_backward_t_kernel(BlendArgs a, int 
     const uint32_t slot_bytes = slot < 0 ? 0u : (uint32_t)slot * 4u;
     const unsigned long long m_out = __builtin_amdgcn_ballot_w64(slot >= 0);            // lanes that carry a sum
     const unsigned long long m_q0 = __builtin_amdgcn_ballot_w64((q & 3) == 0), m_q1 = __builtin_amdgcn_ballot_w64((q & 3) == 1);
-    float* const fh = &s_fac[wave][0][0][0];
-    float* const fw = &s_fac[wave][1][0][0];
+    float* const fhl = &s_fac[wave][0][0][lane];          // this lane's column of the factor slab: [k * WAVE] = slot k
     BtMetaRec* const fmeta = &s_meta[wave][0];
-    const BtLane bl{fh, fw, fp, fmeta + (lane >> 4), lane, q, u0, v0, slot_bytes, m_out, m_q0, m_q1, grad_acc};
+    const BtLane bl{&s_fac[wave][0][0][0], &s_pix[wave][0][0], fmeta, lane, qx0, qy0, slot_bytes, m_out, m_q0, m_q1, grad_acc};
     int k = 0;                      // survivors in the open batch (wave-uniform)
 
     uint32_t gid_n = 0;
@@ -665,9 +673,9 @@ __global__ void __launch_bounds__(256) blend_backward_t_kernel(BlendArgs a, int 
             // leave the two factors in the batch's slot (lane = pixel) and remember whose they are
             // leave the two factors in slot k of the batch (lane = pixel).  Whose they are -- centre and index of the Gaussian --
             // is noted by lane j, which has held all three in registers since it loaded instance j's cull box.
-            fh[k * WAVE + lane] = h;
-            fw[k * WAVE + lane] = w;
-            if (lane == j) fmeta[k] = BtMetaRec{c.x, c.y, gid_l};
+            fhl[k * WAVE] = h;
+            fhl[(BT_SLOTS + k) * WAVE] = w;
+            if (__builtin_amdgcn_inverse_ballot_w64(1ull << j)) fmeta[k] = BtMetaRec{c.x, c.y, gid_l};
             if (++k == BT_SLOTS) {
                 bt_flush<POSE_ONLY>(bl, BT_SLOTS);
                 k = 0;

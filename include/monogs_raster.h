@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define MGS_ABI_VERSION 5
+#define MGS_ABI_VERSION 6
 #define MGS_TILE 16 /* tile edge in pixels; ranges are per 16x16 tile */
 
 /* GaussianRasterizationSettings, minus `prefiltered` / `debug` which are call flags
@@ -289,10 +289,33 @@ int mgs_camera_setup(const float* R, const float* T, const float* projmatrix_raw
  * any of the three outputs may be NULL. */
 int mgs_adam_step(int32_t n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
                   float* const* exp_avg_sq, const uint64_t* numel, const float* lr, double beta1, double beta2,
-                  double eps, int32_t step, int32_t* step_counter, void* stream);
+                  double eps, int32_t step, int32_t* step_counter,
+                  const float* lr_device /* device float[n_tensors] used instead of lr[] when non-NULL: a schedule
+                                            stepped on the device (mgs_lr_schedule_step), hipGraph-replayable */,
+                  void* stream);
 int mgs_densify_stats(int32_t P, const float* viewspace_grad /* [P,3] */, const int32_t* radii,
                       float* xyz_gradient_accum /* [P] */, float* denom /* [P] */, float* max_radii_2d /* [P] */,
                       void* stream);
+/* The statistics of ONE mapping iteration over the n_keyframes <= 32 keyframes a rank rendered, in one launch -- what
+ * /root/reference/utils/slam_mapper.py:400-404,453-460 does keyframe by keyframe after loss.backward():
+ *   visibility_bits[k][w] bit i = (n_touched_k[64 w + i] > 0)   (occ_aware_visibility; uint64 words, ceil(P/64) per keyframe;
+ *                                                                 may be NULL)
+ *   over v = radii_k > 0:  grad_norm[v] += ||grad_means2D_k[v, :2]||,  visible[v] += 1,  max_radii[v] = max(., radii_k[v])
+ * The keyframe tables are HOST arrays of device pointers (grad_means2D[k] may be NULL).  accumulate != 0: the three arrays
+ * are the map's running statistics (xyz_gradient_accum, denom, max_radii_2d) and end up bit for bit as the reference's
+ * loop over keyframes leaves them; accumulate == 0 (keyframe-sharded window): they receive this rank's share of the
+ * iteration only, to be summed / maximised across ranks and folded in with mgs_window_apply. */
+int mgs_window_stats(int32_t P, int32_t n_keyframes, const float* const* grad_means2D, const int32_t* const* radii,
+                     const int32_t* const* n_touched, float* grad_norm /* [P] */, float* visible /* [P] */,
+                     float* max_radii /* [P] */, int32_t accumulate, uint64_t* visibility_bits, void* stream);
+int mgs_window_apply(int32_t P, const float* grad_norm, const float* visible, const float* max_radii,
+                     float* xyz_gradient_accum, float* denom, float* max_radii_2d, void* stream);
+/* GaussianModel.update_learning_rate (/root/reference/gaussian_splatting/scene/gaussian_model.py:451-465, schedule
+ * /root/reference/gaussian_splatting/utils/general_utils.py:79-94) on the device: *iteration += 1, *lr_out = schedule of
+ * the new value -- the mapper's `self.nr_iters` and the xyz group's learning rate, kept in device memory so that a
+ * captured mapping iteration steps them itself. */
+int mgs_lr_schedule_step(int32_t* iteration, float* lr_out, double lr_init, double lr_final, int32_t lr_delay_steps,
+                         double lr_delay_mult, int32_t max_steps, void* stream);
 
 /* ---- Fused map activations ------------------------------------------------
  * rotations = F.normalize(rot_raw), scales3 = exp(scale_raw) (isotropic [P,1] expanded to [P,3] as render() does),

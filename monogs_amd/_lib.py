@@ -11,7 +11,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MGS_LIB_PATH") or os.path.join(_HERE, "lib", "libmonogs_raster.so")   # (override: kernel experiments)
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 c_float_p = C.c_void_p   # device pointers travel as integers (tensor.data_ptr())
 
@@ -67,7 +67,10 @@ SIGNATURES = {
     "mgs_pose_step": (C.c_int, [C.c_void_p] * 12 + [C.c_int32] + [C.c_float] * 7
                       + [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p] + [C.c_void_p] * 4 + [C.c_void_p]),
     "mgs_pose_step_batch": (C.c_int, [C.c_int32, C.POINTER(C.c_void_p)] + [C.c_float] * 7 + [C.c_int32, C.c_void_p]),
-    "mgs_adam_step": (C.c_int, [C.c_int32] + [C.c_void_p] * 6 + [C.c_double] * 3 + [C.c_int32, C.c_void_p, C.c_void_p]),
+    "mgs_adam_step": (C.c_int, [C.c_int32] + [C.c_void_p] * 6 + [C.c_double] * 3 + [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mgs_window_stats": (C.c_int, [C.c_int32, C.c_int32] + [C.c_void_p] * 6 + [C.c_int32, C.c_void_p, C.c_void_p]),
+    "mgs_window_apply": (C.c_int, [C.c_int32] + [C.c_void_p] * 7),
+    "mgs_lr_schedule_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_int32, C.c_double, C.c_int32, C.c_void_p]),
     "mgs_densify_stats": (C.c_int, [C.c_int32] + [C.c_void_p] * 6),
     "mgs_sum_buffers": (C.c_int, [C.c_int32, C.POINTER(C.c_void_p), C.c_void_p, C.c_uint64, C.c_void_p]),
     "mgs_activate_forward": (C.c_int, [C.c_int32, C.c_int32] + [C.c_void_p] * 7),

@@ -22,6 +22,7 @@ struct AdamArgs {
     float* v[ADAM_MAX_TENSORS];
     uint64_t end[ADAM_MAX_TENSORS];      // exclusive prefix end of each tensor in the flattened index space
     float lr[ADAM_MAX_TENSORS];
+    const float* lr_dev;                 // [n] learning rates in device memory (a schedule stepped on the device), or NULL: lr[]
     int n;
     double beta1, beta2;                 // doubles, as torch keeps them: 1 - beta and the bias corrections are formed in double
     float eps;
@@ -37,11 +38,12 @@ __global__ void adam_bump_kernel(AdamArgs a, int* step_dev) {
 }
 
 __global__ void __launch_bounds__(256) adam_kernel(AdamArgs a) {
-    __shared__ float s_bc1[ADAM_MAX_TENSORS], s_bc2[ADAM_MAX_TENSORS];
+    __shared__ float s_bc1[ADAM_MAX_TENSORS], s_bc2[ADAM_MAX_TENSORS], s_lr[ADAM_MAX_TENSORS];
     if ((int)threadIdx.x < a.n) {
         const int step = a.step_dev ? a.step_dev[threadIdx.x] : a.step;
         s_bc1[threadIdx.x] = (float)(1.0 - pow(a.beta1, (double)step));
         s_bc2[threadIdx.x] = (float)sqrt(1.0 - pow(a.beta2, (double)step));
+        s_lr[threadIdx.x] = a.lr_dev ? a.lr_dev[threadIdx.x] : a.lr[threadIdx.x];
     }
     __syncthreads();
     const uint64_t total = a.end[a.n - 1];
@@ -57,7 +59,7 @@ __global__ void __launch_bounds__(256) adam_kernel(AdamArgs a) {
         a.m[t][j] = m;
         a.v[t][j] = v;
         const float denom = sqrtf(v) / s_bc2[t] + a.eps;
-        a.param[t][j] -= (a.lr[t] / s_bc1[t]) * (m / denom);
+        a.param[t][j] -= (s_lr[t] / s_bc1[t]) * (m / denom);
     }
 }
 
@@ -77,15 +79,133 @@ __global__ void __launch_bounds__(256) densify_stats_kernel(int P, const float* 
     if (max_radii) max_radii[i] = fmaxf(max_radii[i], (float)r);
 }
 
+// ---- the statistics of ONE mapping iteration over the keyframes a rank rendered -------------
+// What /root/reference/utils/slam_mapper.py does after loss.backward() for every keyframe of the window, in one launch:
+//   occ_aware_visibility[kf] = n_touched_kf > 0                                              (:400-404)   -> packed bits
+//   max_radii_2d[v] = max(max_radii_2d[v], radii_kf[v]);  xyz_gradient_accum[v] += ||dL/dmean2D_kf[v, :2]||;  denom[v] += 1
+//                                                              over v = radii_kf > 0        (:453-460, gaussian_model.py:888-892)
+// The norm is taken per keyframe BEFORE the sum (norm of sums != sum of norms), the keyframes are added in window order --
+// bit for bit what the reference's loop over keyframes leaves in the three arrays when `accumulate` (the single-rank case: the
+// arrays ARE the map's running statistics).  Sharded windows pass accumulate = 0: the arrays then receive this rank's share
+// of the iteration only, travel through the collectives, and mgs_window_apply folds the reduced values into the map's.
+constexpr int WS_MAX_KF = 32;               // the fork's window holds up to 30 keyframes (/root/reference/slam.py:75)
+struct WindowStatsArgs {
+    const float* grad2d[WS_MAX_KF];         // [P,3] each: dL/dmeans2D of the keyframe's render (may be NULL: no gradient)
+    const int32_t* radii[WS_MAX_KF];
+    const int32_t* n_touched[WS_MAX_KF];
+    int K, P, accumulate;
+    float *norm, *vis, *maxr;               // [P] each
+    unsigned long long* bits;               // [K][words]: bit i of word w = (n_touched[64 w + i] > 0); may be NULL
+    size_t words;                           // = ceil(P / 64)
+};
+__global__ void __launch_bounds__(256) window_stats_kernel(WindowStatsArgs a) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool in = i < a.P;
+    float norm = 0.f, vis = 0.f, maxr = 0.f;
+    if (in && a.accumulate) { norm = a.norm[i]; vis = a.vis[i]; maxr = a.maxr[i]; }
+    for (int k = 0; k < a.K; ++k) {
+        const int r = in ? a.radii[k][i] : 0;
+        if (r > 0) {
+            if (a.grad2d[k]) {
+                const float gx = a.grad2d[k][3 * (size_t)i], gy = a.grad2d[k][3 * (size_t)i + 1];
+                norm += sqrtf(gx * gx + gy * gy);
+            }
+            vis += 1.f;
+            maxr = fmaxf(maxr, (float)r);
+        }
+        if (a.bits) {
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(in && a.n_touched[k][i] > 0);
+            if ((threadIdx.x & 63) == 0 && (size_t)(i >> 6) < a.words) a.bits[(size_t)k * a.words + (size_t)(i >> 6)] = m;
+        }
+    }
+    if (in) { a.norm[i] = norm; a.vis[i] = vis; a.maxr[i] = maxr; }
+}
+__global__ void __launch_bounds__(256) window_apply_kernel(int P, const float* __restrict__ d_norm,
+                                                           const float* __restrict__ d_vis, const float* __restrict__ d_maxr,
+                                                           float* __restrict__ accum, float* __restrict__ denom,
+                                                           float* __restrict__ maxr) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    accum[i] += d_norm[i];
+    denom[i] += d_vis[i];
+    maxr[i] = fmaxf(maxr[i], d_maxr[i]);
+}
+// GaussianModel.update_learning_rate (gaussian_model.py:451-465 -> general_utils.helper, :79-94) stepped on the device:
+// iteration += 1; lr = schedule(iteration).  One thread, double precision as the host computes it.
+__global__ void lr_schedule_kernel(int* iteration, float* lr_out, double lr_init, double lr_final, int delay_steps,
+                                   double delay_mult, int max_steps) {
+    const int it = iteration[0] + 1;
+    iteration[0] = it;
+    double lr = 0.0;
+    if (it >= 0 && !(lr_init == 0.0 && lr_final == 0.0)) {
+        double delay = 1.0;
+        if (delay_steps > 0) {
+            const double x = fmin(fmax((double)it / (double)delay_steps, 0.0), 1.0);
+            delay = delay_mult + (1.0 - delay_mult) * sin(0.5 * 3.14159265358979323846 * x);
+        }
+        const double t = fmin(fmax((double)it / (double)max_steps, 0.0), 1.0);
+        lr = delay * exp(log(lr_init) * (1.0 - t) + log(lr_final) * t);
+    }
+    lr_out[0] = (float)lr;
+}
+
 }  // namespace mgs
 
 using namespace mgs;
 
 extern "C" {
 
+int mgs_window_stats(int32_t P, int32_t n_keyframes, const float* const* grad_means2D, const int32_t* const* radii,
+                     const int32_t* const* n_touched, float* grad_norm, float* visible, float* max_radii,
+                     int32_t accumulate, uint64_t* visibility_bits, void* stream) {
+    if (P < 0 || n_keyframes < 0 || n_keyframes > WS_MAX_KF) { set_error("mgs_window_stats: 0..32 keyframes"); return 1; }
+    if (P == 0 || n_keyframes == 0) return 0;
+    if (!grad_means2D || !radii || !grad_norm || !visible || !max_radii || (visibility_bits && !n_touched)) {
+        set_error("mgs_window_stats: NULL argument");
+        return 1;
+    }
+    WindowStatsArgs a;
+    for (int k = 0; k < WS_MAX_KF; ++k) {
+        const bool on = k < n_keyframes;
+        if (on && (!radii[k] || (visibility_bits && !n_touched[k]))) { set_error("mgs_window_stats: NULL keyframe tensor"); return 1; }
+        a.grad2d[k] = on ? grad_means2D[k] : nullptr;
+        a.radii[k] = on ? radii[k] : nullptr;
+        a.n_touched[k] = (on && n_touched) ? n_touched[k] : nullptr;
+    }
+    a.K = n_keyframes; a.P = P; a.accumulate = accumulate ? 1 : 0;
+    a.norm = grad_norm; a.vis = visible; a.maxr = max_radii;
+    a.bits = (unsigned long long*)visibility_bits;
+    a.words = ((size_t)P + 63) / 64;
+    hipLaunchKernelGGL(window_stats_kernel, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+    MGS_HIP(hipGetLastError());
+    return 0;
+}
+
+int mgs_window_apply(int32_t P, const float* grad_norm, const float* visible, const float* max_radii,
+                     float* xyz_gradient_accum, float* denom, float* max_radii_2d, void* stream) {
+    if (P < 0 || (P > 0 && (!grad_norm || !visible || !max_radii || !xyz_gradient_accum || !denom || !max_radii_2d))) {
+        set_error("mgs_window_apply: bad arguments");
+        return 1;
+    }
+    if (P == 0) return 0;
+    hipLaunchKernelGGL(window_apply_kernel, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, P, grad_norm, visible,
+                       max_radii, xyz_gradient_accum, denom, max_radii_2d);
+    MGS_HIP(hipGetLastError());
+    return 0;
+}
+
+int mgs_lr_schedule_step(int32_t* iteration, float* lr_out, double lr_init, double lr_final, int32_t lr_delay_steps,
+                         double lr_delay_mult, int32_t max_steps, void* stream) {
+    if (!iteration || !lr_out || max_steps <= 0) { set_error("mgs_lr_schedule_step: bad arguments"); return 1; }
+    hipLaunchKernelGGL(lr_schedule_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, iteration, lr_out, lr_init, lr_final,
+                       lr_delay_steps, lr_delay_mult, max_steps);
+    MGS_HIP(hipGetLastError());
+    return 0;
+}
+
 int mgs_adam_step(int32_t n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
                   float* const* exp_avg_sq, const uint64_t* numel, const float* lr, double beta1, double beta2,
-                  double eps, int32_t step, int32_t* step_counter, void* stream) {
+                  double eps, int32_t step, int32_t* step_counter, const float* lr_dev, void* stream) {
     if (n_tensors < 1 || n_tensors > ADAM_MAX_TENSORS) { set_error("mgs_adam_step: 1..8 tensors"); return 1; }
     if (!params || !grads || !exp_avg || !exp_avg_sq || !numel || !lr) { set_error("mgs_adam_step: NULL table"); return 1; }
     if (!step_counter && step < 1) { set_error("step is 1-based"); return 1; }
@@ -103,6 +223,7 @@ int mgs_adam_step(int32_t n_tensors, float* const* params, const float* const* g
         a.lr[t] = on ? lr[t] : 0.f;
     }
     a.n = n_tensors; a.beta1 = beta1; a.beta2 = beta2; a.eps = (float)eps; a.step = step; a.step_dev = step_counter;
+    a.lr_dev = lr_dev;
     if (run == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     if (step_counter) hipLaunchKernelGGL(adam_bump_kernel, dim3(1), dim3(ADAM_MAX_TENSORS), 0, s, a, step_counter);

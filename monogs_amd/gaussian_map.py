@@ -43,6 +43,13 @@ def build_rotation(q: torch.Tensor) -> torch.Tensor:
 # (/root/reference/configs/mono/tum/base_config.yaml:57-65 through gaussian_model.py:405-436)
 DEFAULT_LRS = (1.6e-4 * 6.0, 0.0025, 0.05, 0.001, 0.001)
 NAMES = ("xyz", "f_dc", "opacity", "scaling", "rotation")
+# what the reference itself trains with: training_setup (gaussian_model.py:398-449) on opt_params of
+# /root/reference/configs/mono/tum/base_config.yaml:49-66 with init_lr(6.0) (/root/reference/slam.py:87): position_lr_init
+# 0.0016 and scaling_lr 0.001 are multiplied by spatial_lr_scale = 6; the xyz rate then follows the log-linear schedule
+# of general_utils.helper (no delay: lr_delay_steps = 0) from 0.0096 to 0.0000096 over 30 000 mapping iterations
+REFERENCE_LRS = (0.0016 * 6.0, 0.0025, 0.05, 0.001 * 6.0, 0.001)
+REFERENCE_LR_SCHEDULE = dict(lr_init=0.0016 * 6.0, lr_final=0.0000016 * 6.0, lr_delay_steps=0, lr_delay_mult=0.01,
+                             max_steps=30000)
 
 
 class GaussianMap:

@@ -25,6 +25,7 @@ class GaussianAdam:
         self.exp_avg = [torch.zeros_like(p) for p in self.params]
         self.exp_avg_sq = [torch.zeros_like(p) for p in self.params]
         self.t_dev = torch.zeros(len(self.params), dtype=torch.int32, device=self.params[0].device)   # per-tensor step counts
+        self.lr_dev = None          # device float[n]: learning rates read by the kernel instead of ``lrs`` (device_lrs())
 
     # ---- optimiser-state surgery (map growth / pruning) -----------------------------------------------------
     # What GaussianModel does to torch.optim.Adam's state when the map changes size
@@ -69,6 +70,21 @@ class GaussianAdam:
     def set_lr(self, index: int, lr: float):
         """Learning rate of tensor ``index`` for the following steps (``update_learning_rate`` sets the xyz group's)."""
         self.lrs[index] = float(lr)
+        if self.lr_dev is not None:
+            self.lr_dev[index] = float(lr)
+
+    def device_lrs(self, on: bool = True):
+        """Keep the learning rates in device memory (a captured mapping iteration steps the xyz schedule there,
+        ``mgs_lr_schedule_step``).  Returns the device tensor; ``sync_lrs_from_device`` copies it back into ``lrs``."""
+        if not on:
+            self.lr_dev = None
+        elif self.lr_dev is None:
+            self.lr_dev = torch.tensor(self.lrs, dtype=torch.float32, device=self.params[0].device)
+        return self.lr_dev
+
+    def sync_lrs_from_device(self):
+        if self.lr_dev is not None:
+            self.lrs = [float(x) for x in self.lr_dev.tolist()]
 
     def zero_grad(self, set_to_none=True):
         for p in self.params:
@@ -90,7 +106,8 @@ class GaussianAdam:
         lr = (C.c_float * n)(*self.lrs)
         with _device_guard(self.params[0].device):
             _lib.check(lib.mgs_adam_step(n, tab(self.params), tab(grads), tab(self.exp_avg), tab(self.exp_avg_sq), numel,
-                                         lr, self.betas[0], self.betas[1], self.eps, 0, self.t_dev.data_ptr(), _stream()),
+                                         lr, self.betas[0], self.betas[1], self.eps, 0, self.t_dev.data_ptr(),
+                                         None if self.lr_dev is None else self.lr_dev.data_ptr(), _stream()),
                        "mgs_adam_step")
 
 
@@ -122,6 +139,29 @@ def add_densification_stats(viewspace_grad: torch.Tensor, radii: torch.Tensor, x
     with _device_guard(radii.device):
         _lib.check(lib.mgs_densify_stats(P, g.data_ptr(), radii.contiguous().data_ptr(), p(xyz_gradient_accum), p(denom),
                                          p(max_radii_2d), _stream()), "mgs_densify_stats")
+
+
+def window_stats(grads2d, radii, n_touched, grad_norm, visible, max_radii, accumulate: bool, bits=None):
+    """``mgs_window_stats``: the statistics of one mapping iteration over the keyframes this rank rendered, one launch
+    (/root/reference/utils/slam_mapper.py:400-404,453-460).  ``grads2d[k]`` / ``radii[k]`` / ``n_touched[k]``: per keyframe
+    (a gradient may be None); the three [P] float arrays are updated in place (``accumulate``) or overwritten with this
+    rank's share; ``bits``: int64 [rows >= K, ceil(P/64)] receiving the packed ``n_touched > 0`` bits of keyframe k in row k."""
+    K = len(radii)
+    if K == 0:
+        if not accumulate:
+            grad_norm.zero_(); visible.zero_(); max_radii.zero_()
+        return
+    lib = _lib.load()
+    P = int(radii[0].shape[0])
+    keep = [None if g is None else g.contiguous() for g in grads2d] + [r.contiguous() for r in radii] + \
+           [t.contiguous() for t in n_touched]
+    arr = lambda ts: (C.c_void_p * K)(*[None if t is None else t.data_ptr() for t in ts])  # noqa: E731
+    if bits is not None:
+        assert bits.dtype == torch.int64 and bits.is_contiguous() and bits.shape[0] >= K and bits.shape[1] == (P + 63) // 64
+    with _device_guard(radii[0].device):
+        _lib.check(lib.mgs_window_stats(P, K, arr(keep[:K]), arr(keep[K:2 * K]), arr(keep[2 * K:]), grad_norm.data_ptr(),
+                                        visible.data_ptr(), max_radii.data_ptr(), 1 if accumulate else 0,
+                                        None if bits is None else bits.data_ptr(), _stream()), "mgs_window_stats")
 
 
 class _Activate(torch.autograd.Function):
@@ -182,8 +222,8 @@ class _FanOut(torch.autograd.Function):
     """n aliases of each of m tensors; backward adds the n incoming gradients of every tensor in one launch."""
 
     @staticmethod
-    def forward(ctx, n, *tensors):
-        ctx.n, ctx.m = int(n), len(tensors)
+    def forward(ctx, n, out, *tensors):
+        ctx.n, ctx.m, ctx.out = int(n), len(tensors), out
         ctx.set_materialize_grads(False)
         return tuple(t.view_as(t) for _ in range(int(n)) for t in tensors)
 
@@ -211,12 +251,15 @@ class _FanOut(torch.autograd.Function):
         flats = [flat_of(gs) for gs in live]
         if live and all(f is not None for f in flats) and len({f.numel() for f in flats}) == 1:
             # (the rasteriser's backward carves its map gradients out of one allocation, in argument order)
-            total = flats[0] if len(flats) == 1 else sum_buffers(flats)
+            if ctx.out is not None and ctx.out.numel() == flats[0].numel():
+                total = sum_buffers(flats, out=ctx.out)          # the caller's bucket (one source: a copy into it)
+            else:
+                total = flats[0] if len(flats) == 1 else sum_buffers(flats)
             out, o = [], 0
             for g in live[0]:
                 out.append(total[o:o + g.numel()].view(g.shape))
                 o += g.numel()
-            return (None, *out)
+            return (None, None, *out)
         out = []
         for j in range(m):
             gj = [gs[j] for gs in per if gs[j] is not None]
@@ -231,16 +274,19 @@ class _FanOut(torch.autograd.Function):
                 for g in gj[1:]:
                     acc = acc + g
                 out.append(acc)
-        return (None, *out)
+        if ctx.out is not None:
+            raise RuntimeError("fan_out(out=...): the consumers' gradients do not lie back to back in one buffer each")
+        return (None, None, *out)
 
 
-def fan_out(n: int, *tensors):
+def fan_out(n: int, *tensors, out=None):
     """``n`` tuples of aliases of ``tensors`` for ``n`` consumers (the keyframe renders of a mapping window).  Handing every
     render its own aliases makes the autograd engine deliver the n gradients of each tensor to ONE node, which adds them in
     one launch -- all m tensors at once when a consumer returns its gradients back to back in one buffer, as the
     rasteriser's backward does for (means3D, colours, opacities, scales, rotations) in that order -- instead of n - 1
-    pairwise adds per tensor."""
-    flat = _FanOut.apply(n, *tensors)
+    pairwise adds per tensor.  ``out``: a flat float32 buffer of the summed size that receives the sum (the exchange
+    bucket of a mapping window: the gradients of all keyframes land where the all-reduce reads them)."""
+    flat = _FanOut.apply(n, out, *tensors)
     m = len(tensors)
     return [flat[k * m:(k + 1) * m] for k in range(n)]
 

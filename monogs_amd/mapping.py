@@ -1,36 +1,53 @@
-"""``optimize_map`` -- the mapping-window optimisation that drives the rasteriser, optionally sharded by keyframe
-over the GPUs of a node (BASELINE.json config C4: 8-keyframe window, one keyframe per GPU).
+"""``optimize_map`` / ``initialize_map`` -- the mapping-window optimisation that drives the rasteriser, optionally sharded by
+keyframe over the GPUs of a node (BASELINE.json config C4) and optionally replayed from hipGraphs.
 
-Mirror of ``Mapper.optimize_map`` (/root/reference/utils/slam_mapper.py:244-500): per iteration render every window
-keyframe against the shared Gaussians (:273-324), sum ``get_loss_mapping``, ONE backward (:394), occlusion-aware
-visibility per keyframe (:400-404), covisibility pruning on request (:408-448), ``max_radii_2d`` + densification
-statistics per keyframe (:453-460), ``densify_and_prune`` every ``gaussian_update_every`` iterations (:462-473),
-opacity reset of non-visible Gaussians (:476-479), Adam step on the Gaussians and on the keyframe poses +
-``update_pose`` (:482-496).
+Mirror of ``Mapper.optimize_map`` (/root/reference/utils/slam_mapper.py:244-500) and ``Mapper.initialize_map`` (:169-242):
+per iteration render every window keyframe against the shared Gaussians (:273-324), sum ``get_loss_mapping``, ONE backward
+(:394), occlusion-aware visibility per keyframe (:400-404), covisibility pruning on request (:408-448), ``max_radii_2d`` +
+densification statistics per keyframe (:453-460), ``densify_and_prune`` every ``gaussian_update_every`` iterations
+(:462-473), opacity reset of non-visible Gaussians (:476-479), Adam step on the Gaussians, ``update_learning_rate``
+(:482-484), Adam on the keyframe poses + ``update_pose`` (:486-496).
 
-Sharding (`monogs_amd.window`): rank r renders the window positions ``k % world == r``; the
-Gaussians are replicated.  Per iteration the ranks exchange
-  * ONE all-reduce(SUM) of the Gaussian gradients (12 floats per Gaussian) with the two densification statistics
-    (sum over keyframes of the per-keyframe screen-space gradient norm, and of the visibility count) riding along,
-  * one all-reduce(MAX) of ``max_radii_2d``,
-  * an all-gather of P visibility bits per keyframe,
-and afterwards every rank applies the same Adam step and the same (identically seeded) map surgery, so the replicas
-stay bit-identical with no broadcast of parameters.  Pose / exposure parameters and their optimiser state live on
-the owning rank only; ``sync_poses`` all-gathers them before the map is handed on (:553-556).
+ONE implementation of the iteration serves the eager loop, the hipGraph-replayed loop (``use_graph=True``) and the sharded
+loop; it has two halves with the collectives between them:
+
+  front   map activations (one launch) -> every owned keyframe: full render (screen-space gradient holder, radii, n_touched),
+          fused loss value + gradients, the rasteriser's backward; the gradients of all keyframes meet in ONE flat bucket
+          ``[xyz 3 | rgb 3 | opacity 1 | scales 3 | rotation 4 | grad-norm 1 | visible 1] x P`` (``fan_out(out=...)``); one
+          statistics launch for all keyframes (``mgs_window_stats``: per-keyframe ||dL/dmean2D|| + visible count + MAX radii
+          + packed ``n_touched > 0`` bits)
+  [world > 1]  all-reduce(SUM) of the bucket; ONE all-gather carrying MAX radii + visibility bits (MAX taken locally)
+  back    statistics folded into the map's, backward of the activations (one launch, no autograd), fused Adam with the
+          learning rates in device memory, the xyz schedule + iteration count stepped on the device, the owned keyframes'
+          pose steps in one launch.
+
+Nothing in either half synchronises the host, allocates outside the caching allocator or launches a memset / memcpy node, so
+both are captured once per (map size, window) and replayed; map surgery (densify / prune / opacity reset) stays eager
+between replays, on exactly the iterations the reference does it.  Sharding (`monogs_amd.window`):
+rank r renders the window positions ``k % world == r``; the Gaussians are replicated and every rank applies the same Adam
+step and the same (identically seeded) surgery to bit-identical inputs, so the replicas stay bit-identical with no
+parameter broadcast.  Pose / exposure parameters and their optimiser state live on the owning rank only; ``sync_poses``
+all-gathers them before the map is handed on (:553-556).
 """
 from __future__ import annotations
 
 import contextlib
+import math
+import time
 from typing import Dict, List, Optional, Sequence
 
 import torch
 import torch.distributed as dist
 
-from . import fused_losses, window as W
+from . import _lib, camera as cam, fused_losses, rasterizer as _rast, window as W
 from .gaussian_map import GaussianMap
-from .gaussian_optim import activate, add_densification_stats, fan_out
+from .gaussian_optim import activate, fan_out, window_stats
 from .pose_optim import PoseAdam
+from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer, _device_guard, _stream
 from .renderer import render
+
+BUCKET_COLS = 16          # floats per Gaussian in the exchange bucket (see the module docstring)
+_GRAD_COLS = 14
 
 
 def render_map(vp, intr, gmap: GaussianMap, bg):
@@ -41,8 +58,50 @@ def render_map(vp, intr, gmap: GaussianMap, bg):
     return render(vp, intr, gmap.get_xyz, gmap.get_rotation, gmap.get_scaling, gmap.get_opacity, gmap.get_features, bg)
 
 
+class _Plan:
+    """Static state of the window iteration for one (map size, window, loss flavour): everything a captured half points at."""
+
+    def __init__(self, mapper: "WindowMapper", viewpoints: Sequence, init: bool):
+        gmap, dev = mapper.gmap, mapper.gmap.device
+        self.P, self.n, self.init = len(gmap), len(viewpoints), bool(init)
+        self.mine = mapper.owned(self.n)
+        self.vps = [viewpoints[k] for k in self.mine]
+        self.key = (self.P, tuple(id(v) for v in viewpoints), self.init, int(mapper.intr.height), int(mapper.intr.width),
+                    tuple(id(p) for p in gmap.params()))
+        P, f32 = self.P, dict(dtype=torch.float32, device=dev)
+        self.sd = int(gmap._scaling.shape[1])
+        self.bucket = torch.zeros(P * BUCKET_COLS, **f32)
+        self.rot, self.scales3, self.opac = torch.empty(P, 4, **f32), torch.empty(P, 3, **f32), torch.empty(P, 1, **f32)
+        self.d_rot, self.d_scale, self.d_opac = torch.empty(P, 4, **f32), torch.empty(P, self.sd, **f32), torch.empty(P, 1, **f32)
+        # the screen-space gradient holders of render() (zeros whose .grad receives dL/dmean2D), one per owned keyframe,
+        # allocated once: the rasteriser never reads their values
+        self.holders = [torch.zeros(P, 3, requires_grad=True, **f32) for _ in self.mine]
+        self.words = (P + 63) // 64
+        self.rows = W.rows_per_rank(self.n, mapper.world)
+        # what travels in the all-gather: MAX radii of this rank's keyframes, then `rows` rows of visibility bits
+        self.g_words = (P + 1) // 2 + self.rows * self.words                  # int64 words: P floats (padded) + the bit rows
+        self.gin = torch.zeros(self.g_words, dtype=torch.int64, device=dev)
+        self.gout = torch.zeros(mapper.world, self.g_words, dtype=torch.int64, device=dev) if mapper.sharded else None
+        self.maxr = self.gin[:(P + 1) // 2].view(torch.float32)[:P]
+        self.bits = self.gin[(P + 1) // 2:].view(self.rows, self.words)
+        self.lgs: List = []
+        self.radii: List = []
+        self.n_touched: List = []
+        self.graphs = None              # (front, back) or (whole,) once captured
+        self.iter_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+
+    def grad_view(self, col0: int, cols: int):
+        P = self.P
+        return self.bucket[P * col0:P * (col0 + cols)].view(P, cols)
+
+
 class WindowMapper:
-    # the values hard-coded in the fork's mapper (/root/reference/utils/slam_mapper.py:65-89)
+    # the values hard-coded in the fork's mapper (/root/reference/utils/slam_mapper.py:64-89)
+    init_itr_num = 1050
+    init_gaussian_update = 100
+    init_gaussian_reset = 500
+    init_gaussian_th = 0.005
+    init_gaussian_extent = 30.0
     gaussian_update_every = 150
     gaussian_update_offset = 50
     gaussian_th = 0.7
@@ -50,31 +109,39 @@ class WindowMapper:
     gaussian_reset = 2001
     size_threshold = 20
     densify_grad_threshold = 0.0002      # /root/reference/configs/mono/tum/base_config.yaml:66
+    densify_from_iter = 500              # :63
     prune_coviz = 3
 
     def __init__(self, gmap: GaussianMap, intr, bg, group=None, window_size: int = 8, seed: int = 0,
                  lr_rot: float = 0.003 * 0.5, lr_trans: float = 0.001 * 0.5, lr_exposure: float = 0.01,
-                 loss_fn=None):
+                 use_graph: bool = False, force_collectives: bool = False):
+        assert gmap.fused_adam, "WindowMapper drives the fused optimiser (GaussianAdam)"
         self.gmap, self.intr, self.bg, self.group = gmap, intr, bg, group
         self.window_size, self.seed = int(window_size), int(seed)
         self.world, self.rank = W._world(group), W._rank(group)
         self.lrs = (lr_rot, lr_trans, lr_exposure)
-        self.loss_fn = loss_fn or fused_losses.get_loss_mapping
+        self.use_graph = bool(use_graph)
+        # the collectives run when there is more than one rank -- or on request in a one-rank group (a test drives the RCCL
+        # code path of every exchange that way on a one-GPU box)
+        self.sharded = self.world > 1 or (bool(force_collectives) and dist.is_available() and dist.is_initialized())
         self.nr_iters = 0
         self.first_time_pruned = False
         self.occ_aware_visibility: Dict[int, torch.Tensor] = {}     # kf id -> bool[P]
         self._pose_opt: Dict[int, PoseAdam] = {}                    # id(viewpoint) -> optimiser state (owning rank)
-        self.last_loss = None
         self.exposed_comm_s = 0.0       # wall time spent waiting in collectives (diagnostic, synchronises when on)
         self.time_comm = False
-        self._bucket = None
         self.map_surgery = True          # False: no densify_and_prune / opacity reset (fixed-size workloads: benchmarks, tests)
         self.keep_reduced_grads = False  # tests: clones of the (all-reduced) Gaussian gradients of the last iteration
-        self.parallel_keyframes = False  # True: render / back-propagate the owned keyframes on a stream each.  Pays inside a
-                                         # captured iteration (slam_harness: 863 -> 1254 it/s); this eager loop is bound by
-                                         # the host issuing its ~300 launches (C4 on one GPU: 5.04 vs 5.14 ms), so it is off
+        self.parallel_keyframes = None   # render / back-propagate the owned keyframes on a stream each; None: when captured
+                                         # (pays inside a replay: 863 -> 1254 it/s; an eager loop is bound by the host anyway)
+        self.min_graph_iters = 8         # shorter runs are not worth a capture
         self._streams: List = []
         self.last_grads = None
+        self._plan: Optional[_Plan] = None
+        self._carry = None               # gradients a pruning call left behind (see optimize_map)
+        self._pool = None
+        self.stats = dict(captures=0, replays=0, eager_iters=0, capture_s=0.0, replay_s=0.0, replay_kf=0)
+        self.time_replays = False        # measure the replay chunks (one synchronisation at either end of a chunk)
 
     # ---- per-keyframe optimiser state lives on the owning rank ------------------------------------------------------
     def _pose_optimizer(self, vp) -> PoseAdam:
@@ -100,6 +167,266 @@ class WindowMapper:
     def owned(self, n_keyframes: int) -> List[int]:
         return W.shard_keyframes(n_keyframes, self.rank, self.world)
 
+    @property
+    def last_loss(self):
+        """Sum of the owned keyframes' loss values of the last iteration (device scalar), or None."""
+        p = self._plan
+        if p is None or not p.lgs:
+            return None
+        return torch.stack([lg.loss for lg in p.lgs]).sum()
+
+    # ---- plans and graphs ---------------------------------------------------------------------------------------------
+    def _get_plan(self, viewpoints, init) -> _Plan:
+        p = self._plan
+        key = (len(self.gmap), tuple(id(v) for v in viewpoints), bool(init), int(self.intr.height), int(self.intr.width),
+               tuple(id(q) for q in self.gmap.params()))
+        if p is None or p.key != key:
+            self._drop_plan()
+            p = self._plan = _Plan(self, viewpoints, init)
+        return p
+
+    def _drop_plan(self):
+        if self._plan is not None and self._plan.graphs is not None:
+            _rast.clear_graph_flags()
+        self._plan = None
+
+    # ---- the two halves of an iteration -----------------------------------------------------------------------------
+    def _front(self, p: _Plan, accumulate_stats: bool, parallel: bool):
+        """Renders + losses + ONE backward of the owned keyframes into the bucket, then the statistics launch."""
+        gmap, lib, P = self.gmap, _lib.load(), p.P
+        with _device_guard(gmap._xyz.device):
+            _lib.check(lib.mgs_activate_forward(P, p.sd, gmap._rotation.data_ptr(), gmap._scaling.data_ptr(),
+                                                gmap._opacity.data_ptr(), p.rot.data_ptr(), p.scales3.data_ptr(),
+                                                p.opac.data_ptr(), _stream()), "mgs_activate_forward")
+        # the five tensors the renders differentiate with respect to: leaves that CUT the graph at the activations (their
+        # backward is one explicit launch in `_back`, after the collectives)
+        cut = [t.detach().requires_grad_(True) for t in (gmap._xyz, gmap._rgb, p.opac, p.scales3, p.rot)]
+        p.lgs, p.radii, p.n_touched = [], [], []
+        if not p.mine:
+            p.bucket[:P * _GRAD_COLS].zero_()
+        else:
+            fans = fan_out(len(p.mine), *cut, out=p.bucket[:P * _GRAD_COLS])
+            streams = self._kf_streams(len(p.mine)) if (parallel and len(p.mine) > 1) else None
+            main = torch.cuda.current_stream() if streams else None
+            outs, grads = [], []
+            for j, vp in enumerate(p.vps):
+                if streams:
+                    streams[j].wait_stream(main)
+                with (torch.cuda.stream(streams[j]) if streams else contextlib.nullcontext()):
+                    xyz_k, feat_k, opac_k, sc_k, rot_k = fans[j]
+                    h = p.holders[j]
+                    h.grad = None
+                    color, radii, depth, n_touched = self._rasterize(vp, xyz_k, rot_k, sc_k, opac_k, feat_k, h)
+                    lg = fused_losses.loss_grads(color, depth, None, vp, tracking=False, init=p.init)
+                outs += [color, depth]
+                grads += [lg.d_render, lg.d_depth]
+                p.lgs.append(lg)
+                p.radii.append(radii)
+                p.n_touched.append(n_touched)
+            # (no join before the backward: every keyframe's backward runs on the stream of its forward, behind it, and the
+            #  node that adds the gradients up waits for all of them)
+            torch.autograd.backward(outs, grads)
+            if streams:
+                for st in streams:
+                    main.wait_stream(st)
+            for vp, lg in zip(p.vps, p.lgs):
+                if lg.has_exposure:         # (added to what a pruning call left there, like autograd's accumulation)
+                    for q, g in ((vp.exposure_a, lg.d_exposure_a), (vp.exposure_b, lg.d_exposure_b)):
+                        q.grad = g if q.grad is None else q.grad + g
+        # ---- per-keyframe statistics, one launch (per-keyframe norm BEFORE any summation)
+        if accumulate_stats:            # single rank: straight into the map's running statistics, in keyframe order
+            norm, vis, maxr = gmap.xyz_gradient_accum, gmap.denom, gmap.max_radii_2d
+        else:
+            norm, vis, maxr = p.grad_view(14, 1), p.grad_view(15, 1), p.maxr
+        window_stats([h.grad for h in p.holders], p.radii, p.n_touched, norm, vis, maxr, accumulate_stats, p.bits)
+
+    def _rasterize(self, vp, xyz, rot, scales3, opac, feat, holder):
+        """The rasteriser call of ``render()`` (/root/reference/gaussian_splatting/gaussian_renderer/__init__.py:52-156)."""
+        intr = self.intr
+        view, full, campos = cam.cached_camera_tensors(vp, vp.R, vp.T, intr.projection_matrix)
+        rs = GaussianRasterizationSettings(
+            image_height=int(intr.height), image_width=int(intr.width),
+            tanfovx=math.tan(intr.FoVx * 0.5), tanfovy=math.tan(intr.FoVy * 0.5), bg=self.bg, scale_modifier=1.0,
+            viewmatrix=view, projmatrix=full, projmatrix_raw=intr.projection_matrix, sh_degree=0, campos=campos,
+            prefiltered=False, debug=False)
+        color, radii, depth, _, n_touched = GaussianRasterizer(rs)(
+            means3D=xyz, means2D=holder, opacities=opac, colors_precomp=feat, scales=scales3, rotations=rot,
+            theta=vp.cam_rot_delta, rho=vp.cam_trans_delta)
+        return color, radii, depth, n_touched
+
+    def _exchange(self, p: _Plan, grads: bool = True):
+        """The collectives of one iteration: SUM of the bucket, one all-gather of MAX radii + visibility bits."""
+        if not self.sharded:
+            return
+        on_gpu = torch.device(self.gmap.device).type == "cuda"
+        if self.time_comm and on_gpu:
+            torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        if grads:
+            W.all_reduce_(p.bucket, group=self.group)
+        W.all_gather_into_(p.gout.view(-1), p.gin, group=self.group)
+        if self.time_comm:
+            if on_gpu:
+                torch.cuda.synchronize()
+            self.exposed_comm_s += time.perf_counter() - t0
+
+    def _back(self, p: _Plan, viewpoints, pose_steps: bool, lr_update: bool, surgery=None):
+        """Statistics into the map, backward of the activations, (eager only: map surgery,) Adam, schedule, pose steps."""
+        gmap, lib, P = self.gmap, _lib.load(), p.P
+        with _device_guard(gmap._xyz.device):
+            if self.sharded:
+                maxr = torch.amax(p.gout[:, :(P + 1) // 2].view(torch.float32)[:, :P], dim=0)
+                _lib.check(lib.mgs_window_apply(P, p.grad_view(14, 1).data_ptr(), p.grad_view(15, 1).data_ptr(),
+                                                maxr.data_ptr(), gmap.xyz_gradient_accum.data_ptr(), gmap.denom.data_ptr(),
+                                                gmap.max_radii_2d.data_ptr(), _stream()), "mgs_window_apply")
+            _lib.check(lib.mgs_activate_backward(P, p.sd, gmap._rotation.data_ptr(), p.scales3.data_ptr(), p.opac.data_ptr(),
+                                                 p.grad_view(10, 4).data_ptr(), p.grad_view(7, 3).data_ptr(),
+                                                 p.grad_view(6, 1).data_ptr(), p.d_rot.data_ptr(), p.d_scale.data_ptr(),
+                                                 p.d_opac.data_ptr(), _stream()), "mgs_activate_backward")
+        # the leaves' gradients, exactly where autograd would have put them -- BEFORE any surgery: densify_and_prune replaces
+        # every tensor (new leaves, no gradient: no step, as torch.optim.Adam), an opacity reset replaces the opacities only
+        for q, g in zip(gmap.params(), (p.grad_view(0, 3), p.grad_view(3, 3), p.d_opac, p.d_scale, p.d_rot)):
+            q.grad = g
+        gaussian_split = bool(surgery(p)) if surgery is not None else False
+        if self.keep_reduced_grads:
+            self.last_grads = [None if q.grad is None else q.grad.clone() for q in gmap.params()]
+        gmap.optimizer.step()                     # (after surgery every .grad is None: no step, as torch.optim.Adam)
+        if lr_update and gmap.lr_schedule is not None:
+            s = gmap.lr_schedule
+            with _device_guard(gmap._xyz.device):
+                _lib.check(lib.mgs_lr_schedule_step(p.iter_dev.data_ptr(), gmap.optimizer.device_lrs().data_ptr(),
+                                                    float(s["lr_init"]), float(s["lr_final"]), int(s.get("lr_delay_steps", 0)),
+                                                    float(s.get("lr_delay_mult", 1.0)), int(s["max_steps"]), _stream()),
+                           "mgs_lr_schedule_step")
+        if pose_steps:
+            moved = [self._pose_optimizer(vp) for vp in p.vps if vp.frame_idx != 0]      # the first frame is the gauge
+            PoseAdam.step_batch(moved)                                                   # one launch
+        return gaussian_split
+
+    def _zero_grads(self, p: Optional[_Plan], viewpoints):
+        """optimizer.zero_grad(set_to_none=True) + keyframe_optimizers.zero_grad(set_to_none=True) (slam_mapper.py:483,487)."""
+        self.gmap.optimizer.zero_grad(set_to_none=True)
+        for k in self.owned(len(viewpoints)):
+            self._pose_optimizer(viewpoints[k]).zero_grad()
+        if p is not None:
+            for h in p.holders:
+                h.grad = None
+
+    # ---- capture ----------------------------------------------------------------------------------------------------
+    def _capture(self, p: _Plan, viewpoints, pose_steps, lr_update):
+        t0 = time.perf_counter()
+        self._zero_grads(p, viewpoints)
+        if self._pool is None:
+            self._pool = torch.cuda.graph_pool_handle()
+        par = True if self.parallel_keyframes is None else bool(self.parallel_keyframes)
+        single = not self.sharded
+        g1 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g1, pool=self._pool):
+            self._front(p, accumulate_stats=single, parallel=par)
+            if single:
+                self._back(p, viewpoints, pose_steps, lr_update)
+        if single:
+            p.graphs = (g1,)
+        else:
+            g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g2, pool=self._pool):
+                self._back(p, viewpoints, pose_steps, lr_update)
+            p.graphs = (g1, g2)
+        self.stats["captures"] += 1
+        self.stats["capture_s"] += time.perf_counter() - t0
+
+    def _replay(self, p: _Plan, n: int):
+        if self.time_replays:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        if len(p.graphs) == 1:
+            for _ in range(n):
+                p.graphs[0].replay()
+        else:
+            for _ in range(n):
+                p.graphs[0].replay()
+                self._exchange(p)
+                p.graphs[1].replay()
+        if self.time_replays:
+            torch.cuda.synchronize()
+            self.stats["replay_s"] += time.perf_counter() - t0
+            self.stats["replay_kf"] += n * p.n
+        self.stats["replays"] += n
+
+    # ---- the loop shared by optimize_map and initialize_map -----------------------------------------------------------
+    def _sync_schedule(self, p: _Plan):
+        """Device copies of the mapper's iteration count and of the learning rates (what the captured schedule steps)."""
+        p.iter_dev.fill_(self.nr_iters)
+        self.gmap.optimizer.device_lrs()
+
+    def _run(self, viewpoints, kf_ids, iters: int, init: bool, pose_steps: bool, lr_update: bool, surgery_at) -> bool:
+        gmap = self.gmap
+        gaussian_split = False
+        done = 0
+        on_gpu = torch.device(gmap.device).type == "cuda"
+        while done < iters:
+            p = self._get_plan(viewpoints, init)
+            self._sync_schedule(p)
+            # iterations until (and including) the next one that does map surgery
+            ahead = 0
+            while done + ahead < iters and surgery_at(self.nr_iters + ahead + 1, done + ahead) is None:
+                ahead += 1
+            plain = ahead                               # iterations without surgery from here
+            if plain > 0:
+                graph_ok = self.use_graph and on_gpu and plain >= self.min_graph_iters
+                # the first one is always eager: it records the capacity hints of this map size (one host read-back per
+                # render), takes in what a pruning call left behind, and is what a capture needs to have run before it
+                self._iterate_eager(p, viewpoints, pose_steps, lr_update, None, parallel=False)
+                n_left = plain - 1
+                if n_left > 0 and graph_ok:
+                    if p.graphs is None:
+                        self._capture(p, viewpoints, pose_steps, lr_update)
+                    self._replay(p, n_left)
+                    self.nr_iters += n_left
+                    if _rast.check_overflow():
+                        raise RuntimeError("binning capacity overflow inside the captured mapping iteration")
+                else:
+                    for _ in range(n_left):
+                        self._iterate_eager(p, viewpoints, pose_steps, lr_update, None, parallel=False)
+                done += plain
+                self._zero_grads(p, viewpoints)
+            if done < iters:                            # the iteration with map surgery in it, eager
+                fn = surgery_at(self.nr_iters + 1, done)
+                gaussian_split |= self._iterate_eager(p, viewpoints, pose_steps, lr_update, fn, parallel=False)
+                self._zero_grads(None, viewpoints)
+                done += 1
+        self._materialise_visibility(kf_ids)
+        if gmap.optimizer.lr_dev is not None and gmap.lr_schedule is not None:
+            gmap.optimizer.sync_lrs_from_device()
+        return gaussian_split
+
+    def _iterate_eager(self, p: _Plan, viewpoints, pose_steps, lr_update, surgery, parallel) -> bool:
+        self.nr_iters += 1
+        self.stats["eager_iters"] += 1
+        self._front(p, accumulate_stats=not self.sharded, parallel=parallel)
+        if self._carry is not None:
+            if self._carry.shape[0] == p.P * _GRAD_COLS:
+                p.bucket[:p.P * _GRAD_COLS] += self._carry
+            self._carry = None
+        self._exchange(p)
+        split = self._back(p, viewpoints, pose_steps, lr_update, surgery)
+        self._zero_grads(p if not split else None, viewpoints)
+        return split
+
+    def _materialise_visibility(self, kf_ids):
+        """``occ_aware_visibility[kf] = n_touched_kf > 0`` of the LAST iteration for every keyframe of the window
+        (/root/reference/utils/slam_mapper.py:400-404; the reference rebuilds the dict every iteration, only the last
+        survives)."""
+        p = self._plan
+        if p is None:
+            return
+        out = {}
+        for k in range(p.n):
+            src = p.bits if not self.sharded else p.gout[k % self.world, (p.P + 1) // 2:].view(p.rows, p.words)
+            words = src[k // self.world]
+            out[kf_ids[k]] = W.unpack_bits(words.view(torch.uint8), p.P)
+        self.occ_aware_visibility = out
+
     # ---- one call = Mapper.optimize_map(cur_kf_list, prune, iters) ------------------------------------------------------
     def optimize_map(self, viewpoints: Sequence, kf_ids: Optional[Sequence[int]] = None, prune: bool = False,
                      iters: int = 1, init: bool = False) -> bool:
@@ -109,125 +436,87 @@ class WindowMapper:
         if n == 0:
             return False
         kf_ids = [int(v.frame_idx) for v in viewpoints] if kf_ids is None else [int(k) for k in kf_ids]
-        gmap = self.gmap
-        mine = self.owned(n)
-        gaussian_split = False
-        for _ in range(iters):
-            self.nr_iters += 1
-            P = len(gmap)
-            pkgs = {}
-            loss = None
-            fans = None
-            if gmap.fused_adam and gmap._rotation.requires_grad and len(mine) > 1:
-                # activations once per iteration, and each render through its own aliases of the five map tensors: their
-                # gradients then meet in ONE node that adds them in one launch (gaussian_optim.fan_out)
-                rot, scales3, opac = activate(gmap._rotation, gmap._scaling, gmap._opacity)
-                fans = fan_out(len(mine), gmap.get_xyz, gmap.get_features, opac, scales3, rot)
-            # the owned keyframes are independent until their losses are added: a stream each (the small latency-bound
-            # kernels of one render overlap the blend kernels of another)
-            streams = self._kf_streams(len(mine)) if (self.parallel_keyframes and len(mine) > 1
-                                                      and torch.device(gmap.device).type == "cuda") else None
-            main = torch.cuda.current_stream() if streams else None
-            terms = []
-            for j, k in enumerate(mine):
-                if streams:
-                    streams[j].wait_stream(main)
-                with (torch.cuda.stream(streams[j]) if streams else contextlib.nullcontext()):
-                    if fans is not None:
-                        xyz_k, feat_k, opac_k, sc_k, rot_k = fans[j]
-                        pkg = render(viewpoints[k], self.intr, xyz_k, rot_k, sc_k, opac_k, feat_k, self.bg)
-                    else:
-                        pkg = render_map(viewpoints[k], self.intr, gmap, self.bg)
-                    if pkg is None:
-                        raise ValueError("Render package is None")
-                    terms.append(self.loss_fn(pkg["render"], pkg["depth"], viewpoints[k], init=init))
-                pkgs[k] = pkg
-            if streams:
-                for st in streams:
-                    main.wait_stream(st)
-            for term in terms:
-                loss = term if loss is None else loss + term
-            if loss is not None:
-                loss.backward()
-            self.last_loss = loss
+        if prune:
+            for _ in range(iters):
+                self._prune_call(viewpoints, kf_ids, init)
+            return False
 
-            with torch.no_grad():
-                # ---- local statistics of the keyframes rendered here (per-keyframe norm BEFORE any summation)
-                d_norm = torch.zeros(P, 1, device=gmap.device)
-                d_vis = torch.zeros(P, 1, device=gmap.device)
-                d_maxr = torch.zeros(P, device=gmap.device)
-                for k in mine:
-                    add_densification_stats(pkgs[k]["viewspace_points"].grad, pkgs[k]["radii"], d_norm, d_vis, d_maxr)
-                # ---- exchanges
-                if self.world > 1:
-                    d_norm, d_vis = self._exchange(d_norm, d_vis, d_maxr)
-                vis = W.all_gather_visibility({k: pkgs[k]["n_touched"] for k in mine}, n, P, self.group)
-                self.occ_aware_visibility = {kf_ids[k]: vis[k] for k in range(n)}
+        def surgery_at(nr_iters, _i):
+            if not self.map_surgery:
+                return None
+            update = nr_iters % self.gaussian_update_every == self.gaussian_update_offset
+            reset = (nr_iters % self.gaussian_reset) == 0 and not update
+            if not (update or reset):
+                return None
 
-                if prune:
-                    # (as the reference: no optimiser step on a pruning call; when the window is not full yet the
-                    #  gradients of this iteration stay in .grad and the next call's backward adds to them)
-                    if n == self.window_size:
-                        self._prune_covisibility(kf_ids)
-                    return False
+            def fn(p):
+                if update:
+                    self.gmap.densify_and_prune(self.densify_grad_threshold, self.gaussian_th, self.gaussian_extent,
+                                                self.size_threshold,
+                                                generator=W.split_generator(self.gmap.device, self.seed, nr_iters))
+                else:       # every keyframe's visibility_filter (radii > 0); only their union matters
+                    self.gmap.reset_opacity_nonvisible([self._union_visible(p)])
+                return True
+            return fn
+        return self._run(viewpoints, kf_ids, iters, init, pose_steps=True, lr_update=True, surgery_at=surgery_at)
 
-                torch.maximum(gmap.max_radii_2d, d_maxr, out=gmap.max_radii_2d)
-                gmap.xyz_gradient_accum += d_norm
-                gmap.denom += d_vis
+    def initialize_map(self, viewpoint, kf_id: Optional[int] = None, iters: Optional[int] = None) -> None:
+        """``Mapper.initialize_map`` (/root/reference/utils/slam_mapper.py:169-242): ``init_itr_num`` single-camera
+        iterations with the ``init`` loss, densify_and_prune every ``init_gaussian_update`` iterations (the first one
+        included, no screen-size limit), ``reset_opacity`` when the iteration count reaches ``init_gaussian_reset`` or
+        ``densify_from_iter``, no learning-rate schedule, no pose step."""
+        iters = self.init_itr_num if iters is None else int(iters)
+        kf_id = int(viewpoint.frame_idx) if kf_id is None else int(kf_id)
 
-                update_gaussian = self.map_surgery and \
-                    self.nr_iters % self.gaussian_update_every == self.gaussian_update_offset
-                if update_gaussian:
-                    gmap.densify_and_prune(self.densify_grad_threshold, self.gaussian_th, self.gaussian_extent,
-                                           self.size_threshold,
-                                           generator=W.split_generator(gmap.device, self.seed, self.nr_iters))
-                    gaussian_split = True
-                if self.map_surgery and (self.nr_iters % self.gaussian_reset) == 0 and not update_gaussian:
-                    # every keyframe's visibility_filter (radii > 0); only their union matters
-                    gmap.reset_opacity_nonvisible([self._union_visible(pkgs, mine, P)])
-                    gaussian_split = True
+        def surgery_at(nr_iters, i):
+            if not self.map_surgery:
+                return None
+            update = i % self.init_gaussian_update == 0
+            reset = nr_iters == self.init_gaussian_reset or nr_iters == self.densify_from_iter
+            if not (update or reset):
+                return None
 
-                if self.keep_reduced_grads:
-                    self.last_grads = [None if p.grad is None else p.grad.clone() for p in gmap.params()]
-                gmap.optimizer.step()
-                gmap.optimizer.zero_grad(set_to_none=True)
-                gmap.update_learning_rate(self.nr_iters)
-                moved = []
-                for k in mine:
-                    vp = viewpoints[k]
-                    po = self._pose_optimizer(vp)
-                    if vp.frame_idx != 0:             # the first frame is the gauge: never moved
-                        moved.append(po)
-                PoseAdam.step_batch(moved)            # the owned keyframes' pose steps in one launch
-                for k in mine:
-                    self._pose_optimizer(viewpoints[k]).zero_grad()
-        return gaussian_split
+            def fn(p):
+                if update:
+                    self.gmap.densify_and_prune(self.densify_grad_threshold, self.init_gaussian_th, self.init_gaussian_extent,
+                                                None, generator=W.split_generator(self.gmap.device, self.seed, nr_iters))
+                if reset:
+                    self.gmap.reset_opacity()
+                return True
+            return fn
+        self._run([viewpoint], [kf_id], iters, init=True, pose_steps=False, lr_update=False, surgery_at=surgery_at)
 
-    # ---- collectives ------------------------------------------------------------------------------------------------
-    def _exchange(self, d_norm, d_vis, d_maxr):
-        import time
-        gmap = self.gmap
-        on_gpu = torch.device(gmap.device).type == "cuda"
-        if self.time_comm and on_gpu:
-            torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        P = len(gmap)
-        if self._bucket is None or self._bucket.buf.shape[0] != P or \
-                any(a is not b for a, b in zip(self._bucket.params, gmap.params())):
-            self._bucket = W.GradBucket(gmap.params(), extra_cols=2)
-        _, gn, vs, _ = W.allreduce_window_grads(gmap.params(), d_norm.reshape(-1), d_vis.reshape(-1),
-                                                d_maxr, group=self.group, bucket=self._bucket)
-        if self.time_comm:
-            if on_gpu:
-                torch.cuda.synchronize()
-            self.exposed_comm_s += time.perf_counter() - t0
-        return gn.reshape(-1, 1).clone(), vs.reshape(-1, 1).clone()
+    # ---- the pruning call (prune=True, one iteration, no optimiser step) --------------------------------------------
+    def _prune_call(self, viewpoints, kf_ids, init):
+        """slam_mapper.py:394-451: render + backward as always, visibility, covisibility pruning when the window is full,
+        return before the statistics and the optimiser steps.  When the window is not full yet the gradients of this
+        iteration STAY in ``.grad`` (nothing zeroes them) and the next call's backward adds to them: they are kept here
+        at the level they are produced (activated tensors, this rank's keyframes only) and join the bucket of the next
+        iteration BEFORE its all-reduce -- so that the sum over ranks counts them once."""
+        self.nr_iters += 1
+        self.stats["eager_iters"] += 1
+        p = self._get_plan(viewpoints, init)
+        # (statistics launch: the bits only; its three sums land in the bucket's statistics columns and are ignored)
+        self._front(p, accumulate_stats=False, parallel=False)
+        self._exchange(p, grads=False)
+        self._materialise_visibility(kf_ids)
+        if len(viewpoints) == self.window_size:
+            self._carry = None
+            self._zero_grads(p, viewpoints)
+            self._prune_covisibility(kf_ids)
+        else:
+            # (the pose / exposure gradients of the owned keyframes stay in their .grad, as in the reference; the next
+            #  backward adds to them)
+            carry = p.bucket[:p.P * _GRAD_COLS].clone()
+            self._carry = carry if (self._carry is None or self._carry.shape != carry.shape) else self._carry + carry
+            for h in p.holders:
+                h.grad = None
 
-    def _union_visible(self, pkgs, mine, P):
-        u = torch.zeros(P, dtype=torch.bool, device=self.gmap.device)
-        for k in mine:
-            u |= pkgs[k]["visibility_filter"]
-        if self.world > 1:
+    def _union_visible(self, p: _Plan):
+        u = torch.zeros(p.P, dtype=torch.bool, device=self.gmap.device)
+        for r in p.radii:
+            u |= r > 0
+        if self.sharded:
             b = u.to(torch.uint8)
             W.all_reduce_(b, op=dist.ReduceOp.MAX, group=self.group)
             u = b.bool()
@@ -248,7 +537,8 @@ class WindowMapper:
         gmap.prune_points(to_prune)
         keep = ~to_prune
         self.occ_aware_visibility = {k: v[keep] for k, v in self.occ_aware_visibility.items()}
+        self._drop_plan()
 
     def sync_poses(self, viewpoints: Sequence):
         """All-gather the owners' keyframe poses / exposures (before ``push_to_frontend``, slam_mapper.py:553-556)."""
-        W.all_gather_poses(viewpoints, self.group)
+        W.all_gather_poses(viewpoints, self.group, force=self.sharded)

@@ -29,7 +29,7 @@ from .renderer import render
 from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
 from . import fused_losses
 from .gaussian_map import GaussianMap
-from .gaussian_optim import activate, fan_out
+from .gaussian_optim import activate
 from .pose_optim import PoseAdam
 from .synthetic import make_scene
 
@@ -93,20 +93,6 @@ def _render(vp, intr, gmap: GaussianMap, bg):
         rot, scales3, opac = activate(gmap._rotation, gmap._scaling, gmap._opacity)
         return render(vp, intr, gmap.get_xyz, rot, scales3, opac, gmap.get_features, bg)
     return render(vp, intr, gmap.get_xyz, gmap.get_rotation, gmap.get_scaling, gmap.get_opacity, gmap.get_features, bg)
-
-
-def _render_lean(vp, intr, xyz, rot, scales3, opac, feat, bg, zero2d):
-    """The rasteriser call of ``render()`` without what an optimisation loop that only needs colour + depth never reads."""
-    view, full, campos = cam.cached_camera_tensors(vp, vp.R, vp.T, intr.projection_matrix)
-    rs = GaussianRasterizationSettings(
-        image_height=int(intr.height), image_width=int(intr.width),
-        tanfovx=math.tan(intr.FoVx * 0.5), tanfovy=math.tan(intr.FoVy * 0.5), bg=bg, scale_modifier=1.0,
-        viewmatrix=view, projmatrix=full, projmatrix_raw=intr.projection_matrix, sh_degree=0, campos=campos,
-        prefiltered=False, debug=False)
-    color, _, depth, _, _ = GaussianRasterizer(rs)(
-        means3D=xyz, means2D=zero2d, opacities=opac, colors_precomp=feat, scales=scales3, rotations=rot,
-        theta=vp.cam_rot_delta, rho=vp.cam_trans_delta)
-    return color, depth
 
 
 class TrackingGraph:
@@ -248,164 +234,66 @@ def make_sequence(n_frames: int, intrinsics="fr3_office", n_gaussians=60000, see
 
 def run_slam(n_frames=12, intrinsics="fr3_office", tracking_itr_num=100, mapping_itr_num=150, window_size=8,
              kf_interval=4, init_itr_num=300, n_gaussians=60000, device="cuda:0", log=None,
-             init_downsample=8, kf_downsample=16, point_size=1.0, fused_losses_on=True, fused_pose_on=True, graph_tracking=False, graph_mapping=False,
-             track_lookahead=1, loss_module=None, parallel_keyframes=None):
+             init_downsample=8, kf_downsample=16, point_size=1.0, graph_tracking=False, graph_mapping=False,
+             track_lookahead=1, map_surgery=False, reference_lrs=False, prune_after_mapping=None):
     """Returns a dict with tracking / mapping FPS, iterations and the trajectory error.
-    ``parallel_keyframes``: the window's keyframes are rendered (and back-propagated) on a stream each -- they are
-    independent until the gradients meet (/root/reference/utils/slam_mapper.py:273-324), and one VGA-sized render fills a
-    fraction of the chip -- with the map's activations evaluated once per iteration instead of once per keyframe.
-    Default: on with ``graph_mapping`` (measured on the synthetic TUM-like run, 26 frames, windows of up to 6 keyframes:
-    863 -> 1254 captured mapping iterations/s)."""
-    if parallel_keyframes is None:
-        parallel_keyframes = bool(graph_mapping)
-    frames, intr = make_sequence(n_frames, intrinsics, n_gaussians, device=device)
-    if not fused_losses_on and loss_module is None:
-        raise ValueError("fused_losses_on=False needs loss_module= (e.g. the PyTorch mirror oracle/slam_losses.py, "
-                         "which is test infrastructure and not importable from the product package)")
-    L = fused_losses if fused_losses_on else loss_module
-    get_loss_mapping, get_loss_tracking = L.get_loss_mapping, L.get_loss_tracking
-    bg = torch.zeros(3, device=device)
-    kf_streams = [torch.cuda.Stream(device=device) for _ in range(window_size + 1)] if parallel_keyframes else []
-    _z2d = {}
 
-    def zero2d(like):       # the rasteriser's means2D argument when nobody asks for its gradient: one zero tensor per map size
-        key = tuple(like.shape)
-        if key not in _z2d:
-            _z2d.clear()
-            _z2d[key] = torch.zeros(like.shape, device=like.device)
-        return _z2d[key]
-    gmap = GaussianMap(device, capturable=graph_mapping)
+    Mapping runs through ``monogs_amd.mapping.WindowMapper`` -- the SAME ``optimize_map`` / ``initialize_map`` the sharded
+    window uses (render every window keyframe with screen-space gradient holder / radii / n_touched, fused losses, one
+    backward, per-keyframe densification statistics + ``max_radii_2d`` + occlusion-aware visibility, fused Adam +
+    learning-rate schedule, pose steps), replayed from hipGraphs when ``graph_mapping``.  Per keyframe, as ``Mapper.run``
+    does (/root/reference/utils/slam_mapper.py:639-722): extend the map, fresh keyframe optimisers, ``optimize_map(iters)``,
+    then ``optimize_map(prune=True, iters=1)`` (``prune_after_mapping``; default: with ``map_surgery``).
+    ``map_surgery``: densify_and_prune / opacity resets on the reference's schedule (off by default: the young synthetic maps
+    of the short test runs do not survive the reference's pruning thresholds).  ``reference_lrs``: the reference's learning
+    rates and xyz schedule (``gaussian_map.REFERENCE_LRS``) instead of the harness's historical ones."""
+    from .gaussian_map import REFERENCE_LRS, REFERENCE_LR_SCHEDULE
+    from .mapping import WindowMapper
+    if prune_after_mapping is None:
+        prune_after_mapping = bool(map_surgery)
+    frames, intr = make_sequence(n_frames, intrinsics, n_gaussians, device=device)
+    bg = torch.zeros(3, device=device)
+    gmap = GaussianMap(device, **(dict(lrs=REFERENCE_LRS) if reference_lrs else {}))
+    if reference_lrs:
+        gmap.lr_schedule = dict(REFERENCE_LR_SCHEDULE)
+    mapper = WindowMapper(gmap, intr, bg, window_size=window_size, use_graph=graph_mapping)
+    mapper.map_surgery = bool(map_surgery)
+    mapper.time_replays = True
     window: List[Viewpoint] = []
-    per_frame, map_loss = [], []      # (frame, tracking iterations) ; (first, last) mapping loss of every eager window call
-    warm_stream = torch.cuda.Stream(device=device) if graph_mapping else None
-    graph_pool = torch.cuda.graph_pool_handle() if graph_mapping else None   # one pool for every capture: no fresh hipMalloc per keyframe
-    stats = dict(map_warmup_s=0.0, map_first_replay_s=0.0, kf_extend_s=0.0, map_capture_s=0.0, map_replay_s=0.0, map_replay_iters=0, track_capture_s=0.0, track_s=0.0, track_iters=0, tracked=0, map_s=0.0, map_iters=0, keyframes=0, renders=0)
+    per_frame, map_loss, window_sizes = [], [], []      # (frame, tracking iterations); (first, last) mapping loss per call
+    stats = dict(kf_extend_s=0.0, track_capture_s=0.0, track_s=0.0, track_iters=0, tracked=0, map_s=0.0, map_iters=0,
+                 keyframes=0, renders=0)
 
     def sync():
         torch.cuda.synchronize()
 
     def map_window(iters, init=False):
-        pose_params = []
-        fused_kf = [PoseAdam(vp, 0.003 * 0.5, 0.001 * 0.5, 0.01) for vp in window[1:]] if fused_pose_on else []
-        for vp in window[1:] if (len(window) > 1 and not fused_pose_on) else []:
-            pose_params += [{"params": [vp.cam_rot_delta], "lr": 0.003 * 0.5},
-                            {"params": [vp.cam_trans_delta], "lr": 0.001 * 0.5},
-                            {"params": [vp.exposure_a], "lr": 0.01}, {"params": [vp.exposure_b], "lr": 0.01}]
-        kf_opt = torch.optim.Adam(pose_params) if pose_params else None
+        """One ``Mapper`` keyframe: the optimisation call, then the pruning call."""
+        it0 = mapper.nr_iters
+        if init:
+            mapper.initialize_map(window[0], iters=1)
+            first = mapper.last_loss
+            if iters > 1:
+                mapper.initialize_map(window[0], iters=iters - 1)
+        else:
+            mapper.new_keyframe_optimizers(window)
+            mapper.optimize_map(window, iters=1)
+            first = mapper.last_loss
+            if iters > 1:
+                mapper.optimize_map(window, iters=iters - 1)
+        last = mapper.last_loss
+        if not init and prune_after_mapping:
+            mapper.optimize_map(window, prune=True, iters=1)
+        if first is not None and last is not None:
+            map_loss.append((first, last))
+        stats["map_iters"] += mapper.nr_iters - it0
+        stats["renders"] += (mapper.nr_iters - it0) * len(window)
+        window_sizes.append(len(window))
 
-        def iteration(parallel=True):
-            if fused_losses_on:          # value + gradients per keyframe, ONE backward through all the renders
-                outs, grads, lgs = [], [], []
-                if gmap.fused_adam and len(window) > 1:
-                    # activations ONCE per iteration; every keyframe renders through its own aliases of the five map tensors,
-                    # so their gradients meet in one node that adds them in one launch (fan_out); no screen-space gradient
-                    # holder and no visibility mask per render (nothing in this loop reads them)
-                    main = torch.cuda.current_stream()
-                    rot, scales3, opac = activate(gmap._rotation, gmap._scaling, gmap._opacity)
-                    fans = fan_out(len(window), gmap.get_xyz, gmap.get_features, opac, scales3, rot)
-                    use_streams = parallel and parallel_keyframes
-                    for (xyz_k, feat_k, opac_k, sc_k, rot_k), vp, st in zip(fans, window, kf_streams or [None] * len(window)):
-                        if use_streams:
-                            st.wait_stream(main)
-                        with torch.cuda.stream(st if use_streams else main):
-                            color, depth = _render_lean(vp, intr, xyz_k, rot_k, sc_k, opac_k, feat_k, bg, zero2d(xyz_k))
-                            lg = fused_losses.loss_grads(color, depth, None, vp, tracking=False, init=init)
-                        outs += [color, depth]
-                        grads += [lg.d_render, lg.d_depth]
-                        lgs.append((vp, lg))
-                    joined = not use_streams
-                else:
-                    joined = True
-                    for vp in window:
-                        pkg = _render(vp, intr, gmap, bg)
-                        lg = fused_losses.loss_grads(pkg["render"], pkg["depth"], None, vp, tracking=False, init=init)
-                        outs += [pkg["render"], pkg["depth"]]
-                        grads += [lg.d_render, lg.d_depth]
-                        lgs.append((vp, lg))
-                # (no join before the backward: every keyframe's backward runs on the stream of its forward, behind it, and the
-                #  node that adds the gradients up waits for all of them; the join comes before the optimiser steps)
-                torch.autograd.backward(outs, grads)
-                if not joined:
-                    for st in kf_streams[:len(window)]:
-                        torch.cuda.current_stream().wait_stream(st)
-                for vp, lg in lgs:
-                    if lg.has_exposure:
-                        vp.exposure_a.grad, vp.exposure_b.grad = lg.d_exposure_a, lg.d_exposure_b
-            else:
-                loss = None
-                for vp in window:
-                    pkg = _render(vp, intr, gmap, bg)
-                    term = get_loss_mapping(pkg["render"], pkg["depth"], vp, init=init)
-                    loss = term if loss is None else loss + term
-                loss.backward()
-            with torch.no_grad():
-                gmap.optimizer.step()
-                gmap.optimizer.zero_grad(set_to_none=True)
-                PoseAdam.step_batch(fused_kf)                   # every keyframe pose of the window in one launch
-                for pa in fused_kf:
-                    pa.zero_grad()
-
-        if graph_mapping and fused_pose_on and fused_losses_on and iters >= 8:
-            # one eager iteration on a side stream (capacity hint for the new map size, lazy state), then capture one and
-            # replay.  The eager one renders the keyframes one after the other: on a stream each it would pull fresh blocks
-            # into six per-stream allocator pools for every new map size (29 ms of hipMalloc per keyframe, measured).
-            from . import rasterizer as _r
-            sync(); tc0 = time.perf_counter()
-            side = warm_stream
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                iteration(parallel=False)
-            torch.cuda.current_stream().wait_stream(side)
-            sync(); tw = time.perf_counter()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, pool=graph_pool):
-                iteration()
-            sync(); tc1 = time.perf_counter()
-            graph.replay()
-            sync(); tr1 = time.perf_counter()
-            for _ in range(iters - 2):
-                graph.replay()
-            sync()
-            stats["map_warmup_s"] += tw - tc0
-            stats.setdefault("map_capture_ms_each", []).append((round(1e3 * (tw - tc0), 2), round(1e3 * (tc1 - tw), 2)))
-            stats["map_first_replay_s"] += tr1 - tc1
-            stats["map_capture_s"] += tc1 - tc0
-            stats["map_replay_s"] += time.perf_counter() - tr1
-            stats["map_replay_iters"] += iters - 2
-            stats["map_iters"] += 0
-            stats["map_iters"] += iters
-            stats["renders"] += iters * len(window)
-            if _r.check_overflow():
-                raise RuntimeError("binning capacity overflow inside the captured mapping graph")
-            _r.clear_graph_flags()
-            del graph
-            return
-        first_last = [None, None]
-        for it_m in range(iters):
-            loss = 0
-            for vp in window:
-                pkg = _render(vp, intr, gmap, bg)
-                loss = loss + get_loss_mapping(pkg["render"], pkg["depth"], vp, init=init)
-                stats["renders"] += 1
-            loss.backward()
-            first_last[0 if it_m == 0 else 1] = loss.detach()
-            with torch.no_grad():
-                gmap.optimizer.step()
-                gmap.optimizer.zero_grad(set_to_none=True)
-                if kf_opt is not None:
-                    kf_opt.step()
-                    kf_opt.zero_grad(set_to_none=True)
-                    for vp in window[1:]:
-                        vp.retract()
-                for pa in fused_kf:
-                    pa.step_and_retract(sync=False)
-                    pa.zero_grad()
-            stats["map_iters"] += 1
-        map_loss.append(tuple(first_last))
-
+    tgraph = None
+    loss = torch.zeros(())
     for i, vp in enumerate(frames):
         if i == 0:
-            tgraph = None
             vp.update_RT(vp.R_gt, vp.T_gt)
             sync(); t0 = time.perf_counter()
             gmap.extend_from_frame(vp, intr, downsample=init_downsample, init=True, point_size=point_size)
@@ -414,52 +302,32 @@ def run_slam(n_frames=12, intrinsics="fr3_office", tracking_itr_num=100, mapping
             sync(); stats["map_s"] += time.perf_counter() - t0
             stats["keyframes"] += 1
             continue
-        # ---- tracking (pose only; the Gaussians still require grad, as in the reference)
+        # ---- tracking (pose only; /root/reference/utils/slam_tracker.py:83-193)
         prev = frames[i - 1]
         vp.update_RT(prev.R.clone(), prev.T.clone())     # the fused pose step updates R, T in place
+        sync(); t0 = time.perf_counter()
         if graph_tracking:
-            sync(); t0 = time.perf_counter()
             if tgraph is None:                       # the map changed (or first frame): capture against the new map
                 tgraph = TrackingGraph(vp, intr, gmap, bg)
                 sync(); stats["track_capture_s"] += time.perf_counter() - t0
             n_it = tgraph.track(vp, tracking_itr_num, lookahead=track_lookahead)
-            sync(); stats["track_s"] += time.perf_counter() - t0
-            stats["track_iters"] += n_it
-            stats["renders"] += n_it
-            stats["tracked"] += 1
-            per_frame.append((i, n_it))
-            loss = torch.zeros(())
-            for p in gmap.params():
-                p.grad = None
         else:
-            pass
-        if fused_pose_on:
             opt = PoseAdam(vp, 0.003, 0.001, 0.01)
-        else:
-            opt = torch.optim.Adam([{"params": [vp.cam_rot_delta], "lr": 0.003}, {"params": [vp.cam_trans_delta], "lr": 0.001},
-                                    {"params": [vp.exposure_a], "lr": 0.01}, {"params": [vp.exposure_b], "lr": 0.01}])
-        sync(); t0 = time.perf_counter()
-        n_eager = 0
-        for it in range(0 if graph_tracking else tracking_itr_num):
-            pkg = _render(vp, intr, gmap, bg)
-            opt.zero_grad()
-            loss = get_loss_tracking(pkg["render"], pkg["depth"], pkg["opacity"], vp)
-            loss.backward()
-            with torch.no_grad():
-                if fused_pose_on:
-                    conv = opt.step_and_retract()
-                else:
-                    opt.step()
-                    conv = vp.retract()
-            stats["track_iters"] += 1
-            stats["renders"] += 1
-            n_eager += 1
-            if conv:
-                break
-        if not graph_tracking:
-            sync(); stats["track_s"] += time.perf_counter() - t0
-            stats["tracked"] += 1
-            per_frame.append((i, n_eager))
+            n_it = 0
+            for it in range(tracking_itr_num):
+                pkg = _render(vp, intr, gmap, bg)
+                opt.zero_grad()
+                loss = fused_losses.get_loss_tracking(pkg["render"], pkg["depth"], pkg["opacity"], vp)
+                loss.backward()
+                n_it += 1
+                with torch.no_grad():
+                    if opt.step_and_retract():
+                        break
+        sync(); stats["track_s"] += time.perf_counter() - t0
+        stats["track_iters"] += n_it
+        stats["renders"] += n_it
+        stats["tracked"] += 1
+        per_frame.append((i, n_it))
         for p in gmap.params():
             p.grad = None
         # ---- keyframe + mapping
@@ -470,7 +338,6 @@ def run_slam(n_frames=12, intrinsics="fr3_office", tracking_itr_num=100, mapping
             sync(); te0 = time.perf_counter()
             gmap.extend_from_frame(vp, intr, downsample=kf_downsample, render_opacity=pkg["opacity"], point_size=point_size)
             sync(); stats["kf_extend_s"] += time.perf_counter() - te0
-            stats.setdefault("kf_extend_ms_each", []).append(round(1e3 * (time.perf_counter() - te0), 2))
             window.append(vp)
             if len(window) > window_size:
                 window.pop(1)
@@ -490,6 +357,7 @@ def run_slam(n_frames=12, intrinsics="fr3_office", tracking_itr_num=100, mapping
     if graph_tracking and tgraph is not None:
         tgraph.close()
     err = torch.stack([(-(f.R.t() @ f.T) + (f.R_gt.t() @ f.T_gt)).norm() for f in frames[1:]])
+    ms = mapper.stats
     out = dict(stats)
     out.update(frames=n_frames, gaussians=int(gmap.get_xyz.shape[0]), width=intr.width, height=intr.height,
                tracking_fps=stats["tracked"] / max(stats["track_s"], 1e-9),
@@ -499,8 +367,10 @@ def run_slam(n_frames=12, intrinsics="fr3_office", tracking_itr_num=100, mapping
                # steady state: graph replays only (no capture, no keyframe insertion, no one-time lazy loading)
                tracking_steady_iters_per_s=(stats["track_iters"] / max(stats["track_s"] - stats["track_capture_s"], 1e-9)
                                             if graph_tracking else None),
-               mapping_steady_iters_per_s=(stats["map_replay_iters"] / max(stats["map_replay_s"], 1e-9)
-                                           if stats["map_replay_iters"] else None),
+               mapping_steady_iters_per_s=(ms["replays"] / max(ms.get("replay_s", 0.0), 1e-9) if ms["replays"] else None),
+               mapping_keyframe_iters_per_s=(ms.get("replay_kf", 0) / max(ms.get("replay_s", 0.0), 1e-9) if ms["replays"] else None),
+               mapping_replays=ms["replays"], mapping_eager_iters=ms["eager_iters"], mapping_captures=ms["captures"],
+               mapping_capture_s=ms["capture_s"], window_sizes=window_sizes,
                kf_extend_ms=1e3 * stats["kf_extend_s"] / max(stats["keyframes"] - 1, 1),
                ate_rmse_m=float(torch.sqrt((err ** 2).mean())),
                track_iters_per_frame=per_frame,
@@ -508,9 +378,8 @@ def run_slam(n_frames=12, intrinsics="fr3_office", tracking_itr_num=100, mapping
                position_error_m=[float(e) for e in err],
                camera_centers=[(-(f.R.t() @ f.T)).cpu() for f in frames],
                camera_centers_gt=[(-(f.R_gt.t() @ f.T_gt)).cpu() for f in frames],
-               map_loss=[(float(a), float(b)) for a, b in map_loss if a is not None and b is not None],
-               fused_losses=bool(fused_losses_on), fused_pose=bool(fused_pose_on), graph_tracking=bool(graph_tracking), graph_mapping=bool(graph_mapping),
-               parallel_keyframes=bool(parallel_keyframes),
+               map_loss=[(float(a), float(b)) for a, b in map_loss],
+               graph_tracking=bool(graph_tracking), graph_mapping=bool(graph_mapping), map_surgery=bool(map_surgery),
                config=dict(tracking_itr_num=tracking_itr_num, mapping_itr_num=mapping_itr_num,
                            window_size=window_size, kf_interval=kf_interval, init_itr_num=init_itr_num))
     return out

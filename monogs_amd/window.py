@@ -227,13 +227,13 @@ def all_gather_visibility(local: Dict[int, torch.Tensor], n_keyframes: int, P: i
 POSE_FLOATS = 14      # R 9, T 3, exposure_a 1, exposure_b 1
 
 
-def all_gather_poses(viewpoints: Sequence, group=None) -> None:
+def all_gather_poses(viewpoints: Sequence, group=None, force: bool = False) -> None:
     """After the window optimisation every rank needs the updated pose and exposure of EVERY keyframe before the map
     is handed to the front end (/root/reference/utils/slam_mapper.py:553-556).  Keyframe k is owned by rank k % world;
     the owners' values overwrite the stale copies on the other ranks, in place."""
     world, rank = _world(group), _rank(group)
     n = len(viewpoints)
-    if world == 1 or n == 0:
+    if (world == 1 and not (force and dist.is_available() and dist.is_initialized())) or n == 0:
         return
     rows = rows_per_rank(n, world)
     dev = viewpoints[0].R.device
@@ -263,10 +263,10 @@ def split_generator(device, base_seed: int, iteration: int) -> torch.Generator:
     return g
 
 
-def replicas_in_sync(tensors: Sequence[torch.Tensor], group=None) -> bool:
+def replicas_in_sync(tensors: Sequence[torch.Tensor], group=None, force: bool = False) -> bool:
     """Cheap divergence check for the replicated map: a 64-bit wrap-around checksum of the raw bits of every tensor,
     compared across ranks with MIN / MAX reductions.  True when every rank holds the same bits."""
-    if _world(group) == 1:
+    if _world(group) == 1 and not (force and dist.is_available() and dist.is_initialized()):
         return True
     sums = []
     for t in tensors:

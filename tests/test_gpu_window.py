@@ -162,3 +162,207 @@ def test_two_rank_window_matches_single_process(native_lib, tmp_path):
     assert torch.equal(r0["poses"][0][0], one["poses"][0][0])
     for k in range(1, N_KF):
         assert _rel(r0["poses"][k][1], one["poses"][k][1]) < 1e-4
+
+
+# ---- round 3: the captured iteration, C4 at its own shape, the pruning call's carried gradients, RCCL ------------------
+def _c4_setup(dev, n_kf, intrinsics, n_gaussians, downsample):
+    from monogs_amd import camera as cam
+    from monogs_amd.gaussian_map import GaussianMap, REFERENCE_LR_SCHEDULE
+    from monogs_amd.slam_harness import make_sequence
+    frames, intr = make_sequence(n_kf, intrinsics, n_gaussians=n_gaussians, device=dev)
+    for i, vp in enumerate(frames):          # keyframe poses slightly off the truth: the pose gradients are non-zero
+        d = cam.se3_exp(torch.tensor([0.002 * i, -0.001 * i, 0.0, 0.0, 0.0005 * i, 0.0], device=dev))
+        Tm = torch.eye(4, device=dev)
+        Tm[:3, :3], Tm[:3, 3] = vp.R_gt, vp.T_gt
+        Tn = d @ Tm
+        vp.update_RT(Tn[:3, :3], Tn[:3, 3])
+    gmap = GaussianMap(dev)
+    gmap.lr_schedule = dict(REFERENCE_LR_SCHEDULE, lr_init=gmap.lrs[0], lr_final=gmap.lrs[0] * 1e-3, max_steps=300)
+    gmap.extend_from_frame(frames[0], intr, downsample=downsample, init=True, point_size=1.0)
+    return frames, intr, gmap
+
+
+def _run_c4(rank, world, port, out, use_graph, n_kf, intrinsics, n_gaussians, downsample, iters, tag):
+    """One mapping call over the whole window (BASELINE config C4 when 8 keyframes at 1200x680), sharded over `world`."""
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from monogs_amd.mapping import WindowMapper
+    from monogs_amd.window import replicas_in_sync
+    dev = "cuda:0"
+    torch.cuda.set_device(0)
+    if world > 1:
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    frames, intr, gmap = _c4_setup(dev, n_kf, intrinsics, n_gaussians, downsample)
+    before = [p.detach().clone() for p in gmap.params()]
+    mapper = WindowMapper(gmap, intr, torch.zeros(3, device=dev), window_size=n_kf, use_graph=use_graph)
+    mapper.map_surgery = False
+    mapper.optimize_map(frames, iters=iters)
+    in_sync = replicas_in_sync(gmap.params() + [gmap.xyz_gradient_accum, gmap.denom, gmap.max_radii_2d] + gmap.optimizer.exp_avg)
+    mapper.sync_poses(frames)
+    torch.save(dict(params=[p.detach().cpu() for p in gmap.params()], before=[b.cpu() for b in before], in_sync=in_sync,
+                    stats=(gmap.xyz_gradient_accum.cpu(), gmap.denom.cpu(), gmap.max_radii_2d.cpu()),
+                    vis={k: v.cpu() for k, v in mapper.occ_aware_visibility.items()}, nr_iters=mapper.nr_iters,
+                    lrs=list(gmap.optimizer.lrs), mstats=dict(mapper.stats), P=len(gmap),
+                    steps=gmap.optimizer.t_dev.cpu(), loss=float(mapper.last_loss) if mapper.last_loss is not None else None,
+                    poses=[(v.R.cpu(), v.T.cpu(), v.exposure_a.data.cpu(), v.exposure_b.data.cpu()) for v in frames]),
+               f"{out}.{tag}.{world}.{rank}")
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _check_windows_agree(a, b, n_kf, iters, tol_update=3e-2):
+    """Two runs of the same window from the same start (different summation orders of float atomics / collectives)."""
+    assert a["nr_iters"] == b["nr_iters"] == iters and a["P"] == b["P"]
+    assert torch.equal(a["steps"], b["steps"]) and int(a["steps"][0]) == iters
+    assert abs(a["lrs"][0] - b["lrs"][0]) <= 1e-7 * b["lrs"][0] and a["lrs"][0] < 0.99 * a["lrs"][1] * 0 + b["lrs"][0] * 1.0000001
+    for x, y, s in list(zip(a["params"], b["params"], b["before"]))[:4]:       # (not the rotations: pure-noise gradients)
+        assert (y - s).abs().max() > 0
+        assert _rel(x - s, y - s) < tol_update, _rel(x - s, y - s)
+    assert _rel(a["stats"][0], b["stats"][0]) < 1e-3                            # sums of per-keyframe gradient norms
+    assert (a["stats"][1] != b["stats"][1]).float().mean() < 1e-3               # visible counts (a radius may flip at 0 / 1)
+    assert (a["stats"][2] != b["stats"][2]).float().mean() < 1e-3
+    assert sorted(a["vis"]) == sorted(b["vis"]) == list(range(n_kf))
+    for k in range(n_kf):
+        assert (a["vis"][k] != b["vis"][k]).float().mean() < 1e-3 and a["vis"][k].any()
+    assert torch.equal(a["poses"][0][0], b["poses"][0][0])                      # keyframe 0 is the gauge
+    for k in range(1, n_kf):
+        assert _rel(a["poses"][k][1], b["poses"][k][1]) < 1e-3
+
+
+def test_captured_window_iteration_equals_eager(native_lib, tmp_path):
+    """The hipGraph-replayed mapping iteration (one eager iteration, one capture, replays) against the same iterations run
+    eagerly: same code (`WindowMapper._front` / `_back`), so the only difference left is summation order; the iteration
+    count, the Adam step counts and the device-stepped xyz learning rate agree exactly."""
+    out, iters = str(tmp_path / "g"), 12
+    args = (4, "fr3_office", 20000, 8, iters)
+    mp.spawn(_run_c4, args=(1, 0, out, False) + args + ("e",), nprocs=1, join=True)
+    mp.spawn(_run_c4, args=(1, 0, out, True) + args + ("g",), nprocs=1, join=True)
+    e, g = torch.load(f"{out}.e.1.0"), torch.load(f"{out}.g.1.0")
+    assert g["mstats"]["captures"] == 1 and g["mstats"]["replays"] == iters - 1 and g["mstats"]["eager_iters"] == 1
+    assert e["mstats"]["replays"] == 0 and e["mstats"]["eager_iters"] == iters
+    _check_windows_agree(g, e, 4, iters)
+    from monogs_amd.gaussian_optim import expon_lr
+    from monogs_amd.gaussian_map import DEFAULT_LRS, REFERENCE_LR_SCHEDULE
+    want = expon_lr(iters, **dict(REFERENCE_LR_SCHEDULE, lr_init=DEFAULT_LRS[0], lr_final=DEFAULT_LRS[0] * 1e-3, max_steps=300))
+    assert abs(g["lrs"][0] - want) <= 1e-6 * want and abs(e["lrs"][0] - want) <= 1e-6 * want    # update_learning_rate(nr_iters)
+
+
+def test_c4_window_two_ranks_match_one_rank_captured(native_lib, tmp_path):
+    """BASELINE config C4 at its own shape: an 8-keyframe window at Replica resolution (1200x680,
+    /root/reference/configs/rgbd/replica/base_config.yaml:27-28,39-48), ~100 k Gaussians, keyframes sharded over 2 ranks
+    (gloo staged through host memory: RCCL refuses two ranks on one device), both runs on captured iterations."""
+    out, iters, n_kf = str(tmp_path / "c4"), 10, 8
+    args = (n_kf, "replica", 150000, 8, iters)
+    mp.spawn(_run_c4, args=(2, _free_port(), out, True) + args + ("c",), nprocs=2, join=True)
+    mp.spawn(_run_c4, args=(1, 0, out, True) + args + ("c",), nprocs=1, join=True)
+    r0, r1, one = (torch.load(f"{out}.c.{w}.{r}") for w, r in ((2, 0), (2, 1), (1, 0)))
+    assert r0["P"] > 80000
+    assert r0["in_sync"] and r1["in_sync"]
+    for a, b in zip(r0["params"], r1["params"]):
+        assert torch.equal(a, b)                                   # replicas bit-identical, no parameter broadcast
+    for pa, pb in zip(r0["poses"], r1["poses"]):
+        for a, b in zip(pa, pb):
+            assert torch.equal(a, b)                               # after sync_poses
+    assert r0["mstats"]["captures"] == 1 and r0["mstats"]["replays"] == iters - 1
+    _check_windows_agree(r0, one, n_kf, iters)
+
+
+def _run_prune_carry(rank, world, port, out):
+    """A pruning call on a window that is NOT full keeps its gradients (no optimiser step, nothing zeroes them); the next
+    iteration's backward adds to them (/root/reference/utils/slam_mapper.py:394-451,482-483).  Sharded: they must be summed
+    over the ranks ONCE."""
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from monogs_amd.mapping import WindowMapper
+    dev = "cuda:0"
+    torch.cuda.set_device(0)
+    if world > 1:
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    frames, intr, gmap = _c4_setup(dev, 3, "fr3_office", 20000, 8)
+    mapper = WindowMapper(gmap, intr, torch.zeros(3, device=dev), window_size=8)       # window of 3 < 8: not full
+    mapper.map_surgery = False
+    mapper.keep_reduced_grads = True
+    mapper.optimize_map(frames, iters=1)
+    plain = [g.cpu() for g in mapper.last_grads]
+    n_before = len(gmap)
+    mapper.optimize_map(frames, prune=True, iters=1)
+    vis_after_prune = {k: v.cpu() for k, v in mapper.occ_aware_visibility.items()}
+    steps_after_prune = gmap.optimizer.t_dev.cpu().clone()
+    mapper.optimize_map(frames, iters=1)
+    carried = [g.cpu() for g in mapper.last_grads]
+    mapper.optimize_map(frames, iters=1)
+    after = [g.cpu() for g in mapper.last_grads]
+    torch.save(dict(plain=plain, carried=carried, after=after, n=(n_before, len(gmap)), vis=vis_after_prune,
+                    steps=(steps_after_prune, gmap.optimizer.t_dev.cpu()), nr_iters=mapper.nr_iters), f"{out}.{world}.{rank}")
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_pruning_call_gradients_are_carried_once(native_lib, tmp_path):
+    out = str(tmp_path / "p")
+    mp.spawn(_run_prune_carry, args=(2, _free_port(), out), nprocs=2, join=True)
+    mp.spawn(_run_prune_carry, args=(1, 0, out), nprocs=1, join=True)
+    r0, r1, one = (torch.load(f"{out}.{w}.{r}") for w, r in ((2, 0), (2, 1), (1, 0)))
+    assert one["n"][0] == one["n"][1] and one["nr_iters"] == 4                 # window not full: nothing pruned
+    assert int(one["steps"][0][0]) == 1 and int(one["steps"][1][0]) == 3      # the pruning call takes no optimiser step
+    assert len(one["vis"]) == 3 and all(v.any() for v in one["vis"].values())
+    for c, a, pl in zip(one["carried"][:4], one["after"][:4], one["plain"][:4]):
+        # the iteration after the pruning call steps on (pruning call's gradient + its own) ~ twice a plain gradient;
+        # the one after that is plain again
+        assert 1.6 < (c.norm() / a.norm()).item() < 2.4, (c.norm() / a.norm()).item()
+        assert 0.7 < (a.norm() / pl.norm()).item() < 1.4
+    for k in ("plain", "carried", "after"):
+        for a, b, c in zip(r0[k], r1[k], one[k]):
+            assert torch.equal(a, b)
+            assert (a.double() - c.double()).norm() <= 2e-4 * c.double().norm() + 1e-7, (k, _rel(a, c))
+
+
+def _run_rccl_one_rank(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from monogs_amd.mapping import WindowMapper
+    from monogs_amd.window import replicas_in_sync
+    dev = "cuda:0"
+    torch.cuda.set_device(0)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(dev))
+    frames, intr, gmap = _c4_setup(dev, 3, "fr3_office", 20000, 8)
+    res = {}
+    for graph in (False, True):
+        mapper = WindowMapper(gmap, intr, torch.zeros(3, device=dev), window_size=3, use_graph=graph, force_collectives=True)
+        mapper.map_surgery = False
+        mapper.keep_reduced_grads = True
+        mapper.prune_coviz = 1                   # (three keyframes: the reference's "seen by at most 3" would drop the whole map)
+        assert mapper.sharded and mapper.world == 1
+        mapper.optimize_map(frames, iters=10 if graph else 2)
+        mapper.optimize_map(frames, prune=True, iters=1)                   # full window: all-gather of the bits only, then prune
+        mapper.sync_poses(frames)                                           # all-gather of 14 floats per keyframe
+        res[graph] = dict(sync=replicas_in_sync(gmap.params(), force=True),                       # int64 MIN / MAX
+                          sync_bad=replicas_in_sync([torch.full((3,), float("nan"), device=dev)], force=True),
+                          vis=[bool(v.any()) for v in mapper.occ_aware_visibility.values()], P=len(gmap),
+                          stats=dict(mapper.stats), finite=all(bool(torch.isfinite(p).all()) for p in gmap.params()),
+                          accum=float(gmap.xyz_gradient_accum.abs().sum()), maxr=float(gmap.max_radii_2d.max()))
+    torch.save(dict(res=res, backend=dist.get_backend()), out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_exchanges_run_on_rccl_with_one_rank(native_lib, tmp_path):
+    """Every collective of the sharded window executed by the RCCL backend (`nccl`) in a one-rank group on cuda:0: the
+    in-place all-reduce(SUM) of the flat gradient bucket, the int64 all-gather carrying MAX radii + visibility bits, the
+    pose all-gather, the uint8 MAX of the opacity-reset union, the int64 MIN / MAX of `replicas_in_sync` -- eager and
+    between the two captured halves of the iteration."""
+    out = str(tmp_path / "rccl.pt")
+    mp.spawn(_run_rccl_one_rank, args=(1, _free_port(), out), nprocs=1, join=True)
+    r = torch.load(out)
+    assert r["backend"] == "nccl"
+    for graph in (False, True):
+        x = r["res"][graph]
+        assert x["sync"] and x["finite"] and all(x["vis"]) and x["accum"] > 0 and x["maxr"] > 0
+        assert x["sync_bad"]            # (one rank always agrees with itself: the reductions ran and returned)
+    assert r["res"][True]["stats"]["captures"] >= 1 and r["res"][True]["stats"]["replays"] >= 8

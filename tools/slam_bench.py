@@ -24,26 +24,35 @@ if __name__ == "__main__":
     ap.add_argument("--frames", type=int, default=11)
     ap.add_argument("--init-iters", type=int, default=300)
     ap.add_argument("--mapping-iters", type=int, default=None)
+    ap.add_argument("--tracking-iters", type=int, default=None)
+    ap.add_argument("--window", type=int, default=None)
+    ap.add_argument("--kf-interval", type=int, default=None)
     ap.add_argument("--gaussians", type=int, default=60000)
-    ap.add_argument("--graph", action="store_true", help="capture the tracking iteration in a hipGraph (capacity mode)")
+    ap.add_argument("--graph", action="store_true", help="replay the tracking and the mapping iteration from hipGraphs (capacity mode)")
     ap.add_argument("--eager-mapping", action="store_true", help="with --graph: capture tracking only")
-    ap.add_argument("--torch-pose", action="store_true", help="torch.optim.Adam + Python retraction instead of mgs_pose_step")
-    ap.add_argument("--torch-losses", action="store_true", help="use the plain PyTorch losses instead of the fused HIP ones")
-    ap.add_argument("--serial-kf", action="store_true", help="render the window's keyframes one after the other (default with --graph: a stream each)")
+    ap.add_argument("--surgery", action="store_true", help="densify_and_prune / opacity resets / covisibility pruning on the reference's schedule")
+    ap.add_argument("--reference-lrs", action="store_true", help="the reference's learning rates + xyz schedule")
+    ap.add_argument("--fork", action="store_true",
+                    help="the values the fork hard-codes over its YAML (/root/reference/utils/slam_tracker.py:70-72, "
+                         "utils/slam_mapper.py:64-89,660-662, slam.py:75): tracking 100, every frame a keyframe, init 1050, "
+                         "300 iterations per keyframe, window 30")
     ap.add_argument("--lookahead", type=int, default=1, choices=[0, 1],
                     help="with --graph: read the convergence flag of tracking iteration n-1 while n runs")
     a = ap.parse_args()
     from monogs_amd.slam_harness import run_slam
-    loss_module = None
-    if a.torch_losses:          # measurement tool only: the PyTorch mirror lives with the test infrastructure
-        from oracle import slam_losses as loss_module
     cfg = dict(CONFIGS[a.config])
-    if a.mapping_iters is not None:
-        cfg["mapping_itr_num"] = a.mapping_iters
-    out = run_slam(n_frames=a.frames, init_itr_num=a.init_iters, n_gaussians=a.gaussians,
-                   fused_losses_on=not a.torch_losses, fused_pose_on=not a.torch_pose, graph_tracking=a.graph, graph_mapping=a.graph and not a.eager_mapping, track_lookahead=a.lookahead, loss_module=loss_module, parallel_keyframes=False if a.serial_kf else None,
-                   log=lambda s: print("[slam]", s, file=sys.stderr, flush=True), **cfg)
-    out["workload"] = f"synthetic {a.config}-like sequence, {a.frames} frames"
+    init_iters = a.init_iters
+    if a.fork:
+        cfg.update(tracking_itr_num=100, mapping_itr_num=300, window_size=30, kf_interval=1)
+        init_iters = 1050
+    for k, v in (("mapping_itr_num", a.mapping_iters), ("tracking_itr_num", a.tracking_iters), ("window_size", a.window),
+                 ("kf_interval", a.kf_interval)):
+        if v is not None:
+            cfg[k] = v
+    out = run_slam(n_frames=a.frames, init_itr_num=init_iters, n_gaussians=a.gaussians, graph_tracking=a.graph,
+                   graph_mapping=a.graph and not a.eager_mapping, track_lookahead=a.lookahead, map_surgery=a.surgery,
+                   reference_lrs=a.reference_lrs, log=lambda s: print("[slam]", s, file=sys.stderr, flush=True), **cfg)
+    out["workload"] = f"synthetic {a.config}-like sequence, {a.frames} frames" + (" (fork's hard-coded run configuration)" if a.fork else "")
     for k in ("poses", "camera_centers", "camera_centers_gt"):      # tensors: not JSON
         out.pop(k, None)
     print(json.dumps(out))

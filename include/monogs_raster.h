@@ -172,6 +172,13 @@ int mgs_backward(const mgs_camera* cam, int32_t P, uint64_t num_rendered,
                  float* dL_dtau,      /* [6]   */
                  void* backward_scratch, int32_t scratch_prepared, mgs_timing* timing, void* stream);
 
+/* Diagnostic: MGS_VALU_CEILING_BLOCKS x 256 threads (8 waves per SIMD on all 256 compute units) run `iters` trips of 8
+ * independent v_fma_f32 each and store one float per thread into out[MGS_VALU_CEILING_BLOCKS * 256].  Timed by the caller,
+ * 8 * iters * MGS_VALU_CEILING_BLOCKS * 4 wave-instructions / time is the plain-FMA issue rate this chip sustains (the
+ * ceiling bench.py quotes next to the 1228.8 G wave-inst/s of the data sheet). */
+#define MGS_VALU_CEILING_BLOCKS 2048
+int mgs_debug_valu_ceiling(float* out, int32_t iters, void* stream);
+
 /* Diagnostic (not on the hot path): counts what the blend backward of the matching forward does, into
  * stats_dev[8] (device uint64): [0] 64-instance steps walked, [1] instances that pass the per-quadrant cull and are
  * fetched ("survivors"), [2] survivors with >= 1 active pixel (= wave reductions = atomic instructions),

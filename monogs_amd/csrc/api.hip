@@ -319,6 +319,11 @@ int mgs_debug_blend_stats(const mgs_camera* cam, int32_t P, uint64_t R, const vo
     return launch_blend_backward_stats(*cam, g, b, img, (unsigned long long*)stats_dev, s);
 }
 
+int mgs_debug_valu_ceiling(float* out, int32_t iters, void* stream) {
+    if (!out || iters < 1) { set_error("mgs_debug_valu_ceiling: bad arguments"); return 1; }
+    return launch_valu_ceiling(out, iters, (hipStream_t)stream);
+}
+
 int mgs_debug_set_radix_spin_limit(uint32_t limit) { return set_radix_spin_limit(limit); }
 
 int mgs_debug_set_option(const char* name, int64_t value) {

@@ -788,4 +788,21 @@ int launch_blend_backward(const mgs_camera& cam, const GeometryState& g, const B
     return 0;
 }
 
+// ---- diagnostic: the plain-FMA issue ceiling of this chip, measured by whoever asks (bench.py prints it next to the spec
+// VALU peak).  8 waves per SIMD, every CU busy, 8 independent v_fma_f32 per trip: tools/ubench/valu_rate.hip's first row.
+__global__ void __launch_bounds__(256) valu_ceiling_kernel(float* out, int iters, float seed) {
+    float a0 = seed + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    const float c = 1.0001f, d = 0.0001f;
+    for (int i = 0; i < iters; ++i) {
+        a0 = __builtin_fmaf(a0, c, d); a1 = __builtin_fmaf(a1, c, d); a2 = __builtin_fmaf(a2, c, d); a3 = __builtin_fmaf(a3, c, d);
+        a4 = __builtin_fmaf(a4, c, d); a5 = __builtin_fmaf(a5, c, d); a6 = __builtin_fmaf(a6, c, d); a7 = __builtin_fmaf(a7, c, d);
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
+}
+int launch_valu_ceiling(float* out, int iters, hipStream_t s) {
+    hipLaunchKernelGGL(valu_ceiling_kernel, dim3(MGS_VALU_CEILING_BLOCKS), dim3(256), 0, s, out, iters, 1.0f);
+    MGS_HIP(hipGetLastError());
+    return 0;
+}
+
 }  // namespace mgs

@@ -235,6 +235,7 @@ int launch_blend_backward(const mgs_camera& cam, const GeometryState& g, const B
                           float* grad_acc, bool pose_only, hipStream_t s);
 int launch_blend_backward_stats(const mgs_camera& cam, const GeometryState& g, const BinningState& b,
                                 const ImageState& img, unsigned long long* stats, hipStream_t s);
+int launch_valu_ceiling(float* out, int iters, hipStream_t s);
 struct GeomBackwardArgs {
     const float *means3D, *shs, *colors_precomp, *opacities, *scales, *rotations, *cov3D_precomp;
     const int32_t* radii;

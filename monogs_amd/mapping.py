@@ -373,11 +373,16 @@ class WindowMapper:
                 ahead += 1
             plain = ahead                               # iterations without surgery from here
             if plain > 0:
-                graph_ok = self.use_graph and on_gpu and plain >= self.min_graph_iters
-                # the first one is always eager: it records the capacity hints of this map size (one host read-back per
-                # render), takes in what a pruning call left behind, and is what a capture needs to have run before it
-                self._iterate_eager(p, viewpoints, pose_steps, lr_update, None, parallel=False)
-                n_left = plain - 1
+                graph_ok = self.use_graph and on_gpu and (plain >= self.min_graph_iters or p.graphs is not None)
+                # The first iteration of a new plan is always eager: it records the capacity hints of this map size (one host
+                # read-back per render) and is what a capture needs to have run before it.  So is the one that has to take in
+                # what a pruning call left behind (Gaussian gradients in `_carry`, pose gradients in the parameters' .grad).
+                pending = self._carry is not None or any(
+                    q.grad is not None for vp in p.vps for q in (vp.cam_rot_delta, vp.cam_trans_delta, vp.exposure_a, vp.exposure_b))
+                n_left = plain
+                if p.graphs is None or pending or not graph_ok:
+                    self._iterate_eager(p, viewpoints, pose_steps, lr_update, None, parallel=False)
+                    n_left -= 1
                 if n_left > 0 and graph_ok:
                     if p.graphs is None:
                         self._capture(p, viewpoints, pose_steps, lr_update)

@@ -19,7 +19,12 @@ python3 $R/tools/traffic_from_pmc.py $(find /tmp/prof_$tag/pf -name '*counter_co
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d /tmp/prof_$tag/sa -o a -- $B --steps 3 --warmup 1 > /tmp/prof_$tag/sa.log 2>&1
 rocprofv3 --pmc SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INSTS_SMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_WR SQ_WAVES --kernel-trace --output-format csv -d /tmp/prof_$tag/sb -o b -- $B --steps 3 --warmup 1 > /tmp/prof_$tag/sb.log 2>&1
 python3 $R/tools/pmc_to_json.py $O/${tag}_pmc_valu.json $(find /tmp/prof_$tag/sa /tmp/prof_$tag/sb -name '*counter_collection.csv') > $O/${tag}_pmc_sq.txt 2>&1
+# 3b. issue cost per instruction class (micro-benchmark) and the static mix of the backward's hot loop
+$R/tools/ubench/valu_rate > $O/${tag}_ubench_valu_rates.txt 2>&1
+grep '^JSON ' $O/${tag}_ubench_valu_rates.txt | cut -c6- > $O/${tag}_valu_costs.json
+python3 $R/tools/isa_mix.py $O/${tag}_isa_mix.json > /dev/null 2>&1
 # 4. the plain line (with the stamped files in place the roofline record carries traffic and valu)
 cp $O/${tag}_traffic.json $R/profiles/traffic.json; cp $O/${tag}_pmc_valu.json $R/profiles/pmc_valu.json
+cp $O/${tag}_valu_costs.json $R/profiles/valu_costs.json; cp $O/${tag}_isa_mix.json $R/profiles/isa_mix.json
 python3 $R/bench.py > $O/${tag}_bench_default.log 2>&1
 tail -1 $O/${tag}_bench_default.log | cut -c1-2500

@@ -226,5 +226,12 @@ int main() {
     }
     printf("chip-wide plain-FMA issue ceiling measured here: %.1f G wave-inst/s (spec: 1024 SIMDs x 2.4 GHz / 2 = 1228.8)\n",
            1024.0 / fma_ns);
+    // one machine-readable line: ns of SIMD issue per wave-instruction, by the classes tools/isa_mix.py counts
+    auto ns_of = [&](int m) { return ms[m] * 1e6 / (8.0 * iters * per_trip[m]); };
+    printf("JSON {\"valu_plain\": %.4f, \"valu_trans\": %.4f, \"valu_dpp\": %.4f, \"valu_cndmask\": %.4f, "
+           "\"valu_permlane_swap\": %.4f, \"valu_lane\": %.4f, \"lds_swizzle_pipe\": %.4f, \"fma_ginst_s\": %.1f, "
+           "\"unit\": \"ns of SIMD issue per wave-instruction, 8 waves per SIMD, every CU busy\"}\n",
+           fma_ns, 0.5 * (ns_of(M_EXP) + ns_of(M_RCP)), 0.5 * (ns_of(M_DPP_SHR) + ns_of(M_DPP_BANK)), ns_of(M_CND_SALU),
+           0.5 * (ns_of(M_SWAP32) + ns_of(M_SWAP16)), 2.0 * ns_of(M_READLANE) - fma_ns, ns_of(M_SWZ_ONLY), 1024.0 / fma_ns);
     return 0;
 }

@@ -510,7 +510,7 @@ struct __attribute__((aligned(16))) BtMetaRec { float x, y; uint32_t g; };
 // What a lane needs to turn a batch round (all by value: a by-reference lambda ended up as a closure object in scratch).
 struct BtLane {
     const float* fac;               // this wave's factor slab [h | w][slot][pixel] (LDS)
-    const float* pix;               // this wave's dL/dpixel block [q][(rgb,) depth x 4 pixels] (LDS)
+    const float* pix;               // this wave's dL/dpixel block [(rgb,) depth][q][4 pixels] (LDS)
     const BtMetaRec* meta;          // this wave's metadata [slot] {centre x, centre y, Gaussian index} (LDS)
     int lane;
     float qx0, qy0;                 // first pixel of the quadrant (wave-uniform)
@@ -529,7 +529,9 @@ __device__ __forceinline__ void bt_flush(const BtLane L, int n) {
     const float4 h4 = *reinterpret_cast<const float4*>(L.fac + 4 * lane);                   // [row][4 q .. 4 q + 3]
     const float4 w4 = *reinterpret_cast<const float4*>(L.fac + BT_SLOTS * WAVE + 4 * lane);
     const BtMetaRec me = L.meta[row];
-    const float* const fp = L.pix + q * (POSE_ONLY ? 4 : 16);
+    // [channel][q][4]: the sixteen lanes of a row read 256 contiguous bytes per channel (conflict-free; laid out [q][channel]
+    // the 64-byte lane stride put four lanes on every bank: 48 M conflict cycles per launch at C5, r03 PMC)
+    const float* const fp = L.pix + q * 4;
     const float u0 = L.qx0 + (float)(4 * (q & 1)), v0 = L.qy0 + (float)(q >> 1);
     const float dy = me.y - v0;
     const float dx0 = me.x - u0, dx1 = dx0 - 1.f, dx2 = dx0 - 2.f, dx3 = dx0 - 3.f;
@@ -544,8 +546,8 @@ __device__ __forceinline__ void bt_flush(const BtLane L, int n) {
         const float s_z = __builtin_fmaf(w4.w, c3.w, __builtin_fmaf(w4.z, c3.z, __builtin_fmaf(w4.y, c3.y, w4.x * c3.x)));
         m = reduce_rows6(H1, s_y, H2, s_xy, s_yy, s_z, L.m_q0);
     } else {
-        const float4 c0 = *reinterpret_cast<const float4*>(fp), c1 = *reinterpret_cast<const float4*>(fp + 4),
-                     c2 = *reinterpret_cast<const float4*>(fp + 8), c3 = *reinterpret_cast<const float4*>(fp + 12);
+        const float4 c0 = *reinterpret_cast<const float4*>(fp), c1 = *reinterpret_cast<const float4*>(fp + 64),
+                     c2 = *reinterpret_cast<const float4*>(fp + 128), c3 = *reinterpret_cast<const float4*>(fp + 192);
         const float s_r = __builtin_fmaf(w4.w, c0.w, __builtin_fmaf(w4.z, c0.z, __builtin_fmaf(w4.y, c0.y, w4.x * c0.x)));
         const float s_g = __builtin_fmaf(w4.w, c1.w, __builtin_fmaf(w4.z, c1.z, __builtin_fmaf(w4.y, c1.y, w4.x * c1.x)));
         const float s_b = __builtin_fmaf(w4.w, c2.w, __builtin_fmaf(w4.z, c2.z, __builtin_fmaf(w4.y, c2.y, w4.x * c2.x)));
@@ -569,7 +571,7 @@ __global__ void __launch_bounds__(256) blend_backward_t_kernel(BlendArgs a, int 
     // [wave][factor h / w][slot][pixel]: 2 KB per wave
     __shared__ __attribute__((aligned(16))) float s_fac[4][2][BT_SLOTS][WAVE];
     __shared__ BtMetaRec s_meta[4][BT_SLOTS];                                            // [wave][slot] {cx, cy, index}
-    __shared__ __attribute__((aligned(16))) float s_pix[4][16][POSE_ONLY ? 4 : 16];      // [wave][q][(rgb,) depth x 4 pixels]
+    __shared__ __attribute__((aligned(16))) float s_pix[4][POSE_ONLY ? 1 : 4][16][4];    // [wave][(rgb,) depth][q][4 pixels]
     // (the wave number is wave-uniform but computed from a per-lane register: readfirstlane tells the compiler, and the
     //  quadrant origin and the LDS bases derived from it then live in SGPRs -- five VGPRs less)
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
@@ -602,21 +604,20 @@ __global__ void __launch_bounds__(256) blend_backward_t_kernel(BlendArgs a, int 
     // the turned-round view: row = slot of the batch, lane q of the row = pixels 4q .. 4q+3 of the quadrant
     const int q = lane & 15;
     const int fxi = qx0i + 4 * (q & 1), fyi = qy0i + (q >> 1);
-    // dL/dpixel of the lane's four pixels, constants of the launch, live in LDS, [q][channel][pixel] (pose-only: depth only)
+    // dL/dpixel of the lane's four pixels, constants of the launch, live in LDS, [channel][q][pixel] (pose-only: depth only)
     // -- in registers they pushed the kernel past 64 VGPRs -- and come back with four (one) broadcast ds_read_b128 per batch:
     // the four rows read the same addresses.
-    float* const fp = &s_pix[wave][q][0];
     if (lane < 16) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const bool in_i = (fxi + i) < a.W && fyi < a.H;
             const size_t px_i = (size_t)fyi * a.W + fxi + i;
             if (!POSE_ONLY) {
-                fp[0 + i] = in_i ? dL_dcolor[px_i] : 0.f;
-                fp[4 + i] = in_i ? dL_dcolor[HW + px_i] : 0.f;
-                fp[8 + i] = in_i ? dL_dcolor[2 * HW + px_i] : 0.f;
+                s_pix[wave][0][q][i] = in_i ? dL_dcolor[px_i] : 0.f;
+                s_pix[wave][1][q][i] = in_i ? dL_dcolor[HW + px_i] : 0.f;
+                s_pix[wave][2][q][i] = in_i ? dL_dcolor[2 * HW + px_i] : 0.f;
             }
-            fp[(POSE_ONLY ? 0 : 12) + i] = in_i ? dL_ddepth[px_i] : 0.f;
+            s_pix[wave][POSE_ONLY ? 0 : 3][q][i] = in_i ? dL_ddepth[px_i] : 0.f;
         }
     }
     const int slot = POSE_ONLY ? bt_slot6(q) : bt_slot10(q);
@@ -625,7 +626,7 @@ __global__ void __launch_bounds__(256) blend_backward_t_kernel(BlendArgs a, int 
     const unsigned long long m_q0 = __builtin_amdgcn_ballot_w64((q & 3) == 0), m_q1 = __builtin_amdgcn_ballot_w64((q & 3) == 1);
     float* const fhl = &s_fac[wave][0][0][lane];          // this lane's column of the factor slab: [k * WAVE] = slot k
     BtMetaRec* const fmeta = &s_meta[wave][0];
-    const BtLane bl{&s_fac[wave][0][0][0], &s_pix[wave][0][0], fmeta, lane, qx0, qy0, slot_bytes, m_out, m_q0, m_q1, grad_acc};
+    const BtLane bl{&s_fac[wave][0][0][0], &s_pix[wave][0][0][0], fmeta, lane, qx0, qy0, slot_bytes, m_out, m_q0, m_q1, grad_acc};
     int k = 0;                      // survivors in the open batch (wave-uniform)
 
     uint32_t gid_n = 0;

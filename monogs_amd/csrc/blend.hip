@@ -20,6 +20,8 @@
 // alpha < 1/255 and the per-pixel rule would have skipped it too.
 #include "common.h"
 
+#include <type_traits>
+
 
 namespace mgs {
 
@@ -90,6 +92,76 @@ __device__ __forceinline__ Rec fetch(const BlendArgs& a, uint32_t gid_uniform) {
     return Rec{p[R_X], p[R_Y], p[R_CA], p[R_CB], p[R_CC], p[R_OPAC], p[R_R], p[R_G], p[R_B], p[R_DEPTH]};
 }
 
+// One survivor against the 64 pixels of the quadrant.  Round 3: the per-pixel decisions narrow EXEC instead of building
+// lane masks on the scalar unit -- the kernel was bound by the compute unit's ONE scalar ALU (24 scalar instructions per
+// survivor from each of four SIMDs against 28 vector ones; r03 PMC: 86 M SALU + 124 M VALU per launch at C5):
+//     EXEC = live;  v_cmpx (power <= 0);  v_cmpx (alpha >= 1/255)          -> EXEC = pixels this instance acts on
+//     vcc = (T (1 - alpha) < 1e-4): those stop (NOT blended);  EXEC &= ~vcc -> contributors;  live &= ~vcc;
+//     mask = live ? mask : 0          (s_cselect on the SCC of the line before: the walk leaves when the quadrant is done)
+//     w = alpha T;  C += colour w;  D += depth w;  T = T (1 - alpha);  last = position      plain stores under EXEC:
+//                                                                                            no v_cndmask, no mask algebra
+//     [TOUCH] vcc = (T (1 - alpha) > 0.5);  lane j of touched_cnt = popcount(vcc)            (v_writelane ignores EXEC)
+//     EXEC = all
+// One asm block (the compiler must never see a narrowed EXEC): 17 scalar + 23 vector instructions per survivor, 19 + 25
+// while a pixel of the quadrant is still in front of half its light (TOUCH: only then can T (1 - alpha) exceed 0.5).
+template <bool TOUCH>
+__device__ __forceinline__ void blend_one(unsigned long long& live, unsigned long long& mask, float& T, uint32_t& last, float& C0, float& C1, float& C2,
+                                      float& D, const Rec& g, float power, float alpha, uint32_t pos, int j,
+                                      int& touched_cnt) {
+    const float test_T = T * (1.f - alpha);
+    float w;
+    int cnt;
+    if (TOUCH) {
+        asm volatile(
+            "s_mov_b64 exec, %[live]\n\t"
+            "v_cmpx_nlt_f32_e32 vcc, 0, %[power]\n\t"
+            "v_cmpx_ngt_f32_e32 vcc, %[amin], %[alpha]\n\t"
+            "v_cmp_gt_f32_e32 vcc, %[tmin], %[tt]\n\t"
+            "s_andn2_b64 exec, exec, vcc\n\t"
+            "s_andn2_b64 %[live], %[live], vcc\n\t"
+            "s_cselect_b64 %[mask], %[mask], 0\n\t"
+            "v_mul_f32_e32 %[w], %[alpha], %[T]\n\t"
+            "v_mov_b32_e32 %[T], %[tt]\n\t"
+            "v_mov_b32_e32 %[last], %[pos]\n\t"
+            "v_cmp_lt_f32_e32 vcc, 0.5, %[tt]\n\t"
+            "v_fmac_f32_e32 %[C0], %[cr], %[w]\n\t"
+            "v_fmac_f32_e32 %[C1], %[cg], %[w]\n\t"
+            "s_bcnt1_i32_b64 %[cnt], vcc\n\t"
+            "s_mov_b32 m0, %[j]\n\t"
+            "v_fmac_f32_e32 %[C2], %[cb], %[w]\n\t"
+            "v_fmac_f32_e32 %[D], %[cz], %[w]\n\t"
+            "s_mov_b64 exec, -1\n\t"
+            "v_writelane_b32 %[tc], %[cnt], m0\n\t"
+            : [live] "+s"(live), [mask] "+s"(mask), [T] "+v"(T), [last] "+v"(last), [C0] "+v"(C0), [C1] "+v"(C1), [C2] "+v"(C2), [D] "+v"(D),
+              [w] "=&v"(w), [cnt] "=&s"(cnt), [tc] "+v"(touched_cnt)
+            : [power] "v"(power), [alpha] "v"(alpha), [tt] "v"(test_T), [amin] "s"(1.0f / 255.0f), [tmin] "s"(0.0001f),
+              [pos] "s"(pos), [cr] "s"(g.r), [cg] "s"(g.g), [cb] "s"(g.b), [cz] "s"(g.z), [j] "s"(j)
+            : "vcc", "scc", "m0");
+    } else {
+        asm volatile(
+            "s_mov_b64 exec, %[live]\n\t"
+            "v_cmpx_nlt_f32_e32 vcc, 0, %[power]\n\t"
+            "v_cmpx_ngt_f32_e32 vcc, %[amin], %[alpha]\n\t"
+            "v_cmp_gt_f32_e32 vcc, %[tmin], %[tt]\n\t"
+            "s_andn2_b64 exec, exec, vcc\n\t"
+            "s_andn2_b64 %[live], %[live], vcc\n\t"
+            "s_cselect_b64 %[mask], %[mask], 0\n\t"
+            "v_mul_f32_e32 %[w], %[alpha], %[T]\n\t"
+            "v_mov_b32_e32 %[T], %[tt]\n\t"
+            "v_mov_b32_e32 %[last], %[pos]\n\t"
+            "v_fmac_f32_e32 %[C0], %[cr], %[w]\n\t"
+            "v_fmac_f32_e32 %[C1], %[cg], %[w]\n\t"
+            "v_fmac_f32_e32 %[C2], %[cb], %[w]\n\t"
+            "v_fmac_f32_e32 %[D], %[cz], %[w]\n\t"
+            "s_mov_b64 exec, -1\n\t"
+            : [live] "+s"(live), [mask] "+s"(mask), [T] "+v"(T), [last] "+v"(last), [C0] "+v"(C0), [C1] "+v"(C1), [C2] "+v"(C2), [D] "+v"(D),
+              [w] "=&v"(w)
+            : [power] "v"(power), [alpha] "v"(alpha), [tt] "v"(test_T), [amin] "s"(1.0f / 255.0f), [tmin] "s"(0.0001f),
+              [pos] "s"(pos), [cr] "s"(g.r), [cg] "s"(g.g), [cb] "s"(g.b), [cz] "s"(g.z)
+            : "vcc", "scc");
+    }
+}
+
 __global__ void __launch_bounds__(256) blend_forward_kernel(BlendArgs a, float* __restrict__ out_color,
                                                             float* __restrict__ out_depth,
                                                             float* __restrict__ out_opacity,
@@ -126,12 +198,7 @@ __global__ void __launch_bounds__(256) blend_forward_kernel(BlendArgs a, float* 
             ell_n = a.rec[(size_t)gid_n * 4 + 3];
         }
     };
-    if (range.x < range.y) prefetch(range.x + lane);
-    for (uint32_t base = range.x; base < range.y && live != 0ull; base += WAVE) {
-        const uint32_t gid_l = gid_n;
-        const float4 c = box_n, el = ell_n;
-        prefetch(base + WAVE + lane);
-        unsigned long long mask = __builtin_amdgcn_ballot_w64(quadrant_hit(c, el, qx0, qy0, live));
+    auto walk_step = [&](auto touch_tag, uint32_t base, uint32_t gid_l, unsigned long long mask) {
         // n_touched of this step's instances, collected in lane j of one register (v_writelane: one instruction, no
         // branch) and added with ONE vector atomic per step instead of a guarded lane-0 atomic per touched survivor
         int touched_cnt = 0;
@@ -143,31 +210,21 @@ __global__ void __launch_bounds__(256) blend_forward_kernel(BlendArgs a, float* 
             const float dx = g.px - pxf, dy = g.py - pyf;
             const float power = dx * (g.ca * dx + g.cb * dy) + (g.cc * dy) * dy;     // log2 of the Gaussian falloff
             const float alpha = fminf(0.99f, g.op * __builtin_amdgcn_exp2f(power));
-            const float test_T = T * (1.f - alpha);
-            const unsigned long long act = live & __builtin_amdgcn_ballot_w64(!(power > 0.f)) &
-                                           __builtin_amdgcn_ballot_w64(!(alpha < 1.0f / 255.0f));
-            const unsigned long long low = __builtin_amdgcn_ballot_w64(test_T < 0.0001f);
-            const unsigned long long stop = act & low, contrib = act & ~low;
-            live &= ~stop;                                                 // terminated: this instance is NOT blended
-            const bool cb = __builtin_amdgcn_inverse_ballot_w64(contrib);
-            const float w = cb ? alpha * T : 0.f;
-            C0 += g.r * w;
-            C1 += g.g * w;
-            C2 += g.b * w;
-            D += g.z * w;
-            T = cb ? test_T : T;
-            last = cb ? (base - range.x) + (uint32_t)j + 1u : last;
-            const unsigned long long touched = contrib & __builtin_amdgcn_ballot_w64(test_T > 0.5f);
-            // lane j of touched_cnt = popcount: v_writelane_b32 with the lane select in M0 (two SGPR operands exceed the
-            // constant bus; the portable form `lane == j ? cnt : touched_cnt` was v_mov + v_cmp_eq + v_cndmask per survivor).
-            // This kernel has no LDS / GWS / message traffic: nothing else lives in M0.
-            asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0"
-                         : "+v"(touched_cnt)
-                         : "s"((int)__popcll(touched)), "s"(j)
-                         : "m0");
-            if (live == 0ull) break;                                       // the whole quadrant is finished
+            // (also: mask = 0 once no pixel of the quadrant is live -- the walk's only exit test stays `mask != 0`)
+            blend_one<decltype(touch_tag)::value>(live, mask, T, last, C0, C1, C2, D, g, power, alpha,
+                                                  (base - range.x) + (uint32_t)j + 1u, j, touched_cnt);
         }
-        if (touched_cnt != 0) atomicAdd(n_touched + gid_l, touched_cnt);
+        if (decltype(touch_tag)::value && touched_cnt != 0) atomicAdd(n_touched + gid_l, touched_cnt);
+    };
+    if (range.x < range.y) prefetch(range.x + lane);
+    for (uint32_t base = range.x; base < range.y && live != 0ull; base += WAVE) {
+        const uint32_t gid_l = gid_n;
+        const float4 c = box_n, el = ell_n;
+        prefetch(base + WAVE + lane);
+        const unsigned long long mask = __builtin_amdgcn_ballot_w64(quadrant_hit(c, el, qx0, qy0, live));
+        // a pixel counts as "touched" by an instance when T (1 - alpha) > 0.5: impossible once every live pixel has T <= 0.5
+        if ((live & __builtin_amdgcn_ballot_w64(T > 0.5f)) != 0ull) walk_step(std::true_type{}, base, gid_l, mask);
+        else walk_step(std::false_type{}, base, gid_l, mask);
     }
     if (inside) {
         const size_t pix = (size_t)pyi * a.W + pxi, HW = (size_t)a.H * a.W;

@@ -109,6 +109,10 @@ int mgs_forward_preprocess(const mgs_camera* cam, int32_t P,
                            void* geometry, int32_t* radii /* [P] */,
                            void* prepare_backward /* backward scratch to clear, or NULL */,
                            uint64_t* num_rendered /* [host]; NULL = capacity mode, no sync */,
+                           const uint32_t* prev_status /* device, optional: status word of an EARLIER forward on this stream */,
+                           uint32_t* prev_status_out /* [host], optional: receives *prev_status at this call's own
+                                                        synchronisation (num_rendered != NULL): a sort timeout of the exact
+                                                        path cannot pass unseen, and costs no synchronisation of its own */,
                            mgs_timing* timing /* [host] or NULL */, void* stream);
 
 /* Forward, stage 2: duplicate (in depth order), stable grouping by tile, per-tile ranges, front-to-back blend.
@@ -149,6 +153,13 @@ int mgs_forward_render_capacity(const mgs_camera* cam, int32_t P, uint64_t capac
                                 void* geometry, void* binning, void* image,
                                 float* out_color, float* out_depth, float* out_opacity, int32_t* n_touched,
                                 uint32_t* overflow, mgs_timing* timing, void* stream);
+/* Both stages of a capacity-mode forward in ONE call (mgs_forward_preprocess with num_rendered = NULL, then
+ * mgs_forward_render_capacity): what an eager caller pays per crossing of the FFI boundary matters at SLAM sizes. */
+int mgs_forward_capacity(const mgs_camera* cam, int32_t P, const float* means3D, const float* shs,
+                         const float* colors_precomp, const float* opacities, const float* scales, const float* rotations,
+                         const float* cov3D_precomp, void* geometry, int32_t* radii, void* prepare_backward,
+                         uint64_t capacity, void* binning, void* image, float* out_color, float* out_depth,
+                         float* out_opacity, int32_t* n_touched, uint32_t* overflow, mgs_timing* timing, void* stream);
 
 /* Backward.  Consumes dL/dcolor[3,H,W] and dL/ddepth[1,H,W] (dL/dopacity is ignored, as upstream) and
  * the scratch of the matching forward.  Any output pointer may be NULL (that gradient is then not

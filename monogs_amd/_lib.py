@@ -44,7 +44,10 @@ SIGNATURES = {
     "mgs_binning_bytes": (C.c_size_t, [C.c_uint64, C.c_int32, C.c_int32]),
     "mgs_backward_bytes": (C.c_size_t, [C.c_int32]),
     "mgs_forward_preprocess": (C.c_int, [C.POINTER(MgsCamera), C.c_int32] + [C.c_void_p] * 7
-                               + [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(MgsTiming), C.c_void_p]),
+                               + [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p, C.POINTER(C.c_uint32),
+                                  C.POINTER(MgsTiming), C.c_void_p]),
+    "mgs_forward_capacity": (C.c_int, [C.POINTER(MgsCamera), C.c_int32] + [C.c_void_p] * 7 + [C.c_void_p] * 3 + [C.c_uint64]
+                             + [C.c_void_p] * 7 + [C.POINTER(MgsTiming), C.c_void_p]),
     "mgs_forward_render": (C.c_int, [C.POINTER(MgsCamera), C.c_int32, C.c_uint64] + [C.c_void_p] * 8
                            + [C.POINTER(MgsTiming), C.c_void_p]),
     "mgs_debug_set_radix_spin_limit": (C.c_int, [C.c_uint32]),

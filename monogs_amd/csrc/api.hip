@@ -139,11 +139,19 @@ float* mgs_backward_tau(void* backward_scratch, int32_t P) { return backward_tau
 int mgs_forward_preprocess(const mgs_camera* cam, int32_t P, const float* means3D, const float* shs,
                            const float* colors_precomp, const float* opacities, const float* scales,
                            const float* rotations, const float* cov3D_precomp, void* geometry, int32_t* radii,
-                           void* prepare_backward, uint64_t* num_rendered, mgs_timing* timing, void* stream) {
+                           void* prepare_backward, uint64_t* num_rendered, const uint32_t* prev_status,
+                           uint32_t* prev_status_out, mgs_timing* timing, void* stream) {
     if (check_cam(cam)) return 1;
     if (P < 0) { set_error("P must be >= 0"); return 1; }
     if (num_rendered) *num_rendered = 0;        // NULL = capacity mode: no read-back, no stream sync
-    if (P == 0) return 0;
+    if (prev_status_out) *prev_status_out = 0;
+    if (P == 0) {
+        if (prev_status && prev_status_out) {   // nothing to render, but the caller still wants the earlier forward's verdict
+            MGS_HIP(hipMemcpyAsync(prev_status_out, prev_status, sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
+            MGS_HIP(hipStreamSynchronize((hipStream_t)stream));
+        }
+        return 0;
+    }
     if (!means3D || !opacities || !geometry || !radii) { set_error("means3D, opacities, geometry, radii must be non-NULL"); return 1; }
     if ((shs == nullptr) == (colors_precomp == nullptr)) {
         set_error("Please provide excatly one of either SHs or precomputed colors!");
@@ -175,6 +183,10 @@ int mgs_forward_preprocess(const mgs_camera* cam, int32_t P, const float* means3
         MGS_HIP(hipMemcpyAsync(&total, g.scan_blocks + scan_nblocks(P), sizeof(uint32_t), hipMemcpyDeviceToHost, s));   // grand total
         MGS_HIP(hipMemcpyAsync(sort_errors, radix_error_flag(g.sort_temp, (uint64_t)P, 32), sizeof(sort_errors),
                                hipMemcpyDeviceToHost, s));
+        // the status word of an EARLIER forward on this stream rides along: its kernels are done by the time this copy runs,
+        // so a tile-sort timeout of the exact path is seen one forward later at no extra synchronisation
+        if (prev_status && prev_status_out)
+            MGS_HIP(hipMemcpyAsync(prev_status_out, prev_status, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         MGS_HIP(hipStreamSynchronize(s));
         if (sort_errors[0] | sort_errors[1] | sort_errors[2] | sort_errors[3]) { set_error("depth sort: a look-back spin timed out (results invalid)"); return 3; }
         *num_rendered = total;
@@ -243,6 +255,17 @@ int mgs_forward_render_capacity(const mgs_camera* cam, int32_t P, uint64_t capac
     if (capacity == 0) { set_error("capacity must be > 0"); return 1; }
     return forward_render_impl(cam, P, capacity, true, geometry, binning, image, out_color, out_depth, out_opacity,
                                n_touched, overflow, timing, stream);
+}
+
+int mgs_forward_capacity(const mgs_camera* cam, int32_t P, const float* means3D, const float* shs,
+                         const float* colors_precomp, const float* opacities, const float* scales, const float* rotations,
+                         const float* cov3D_precomp, void* geometry, int32_t* radii, void* prepare_backward,
+                         uint64_t capacity, void* binning, void* image, float* out_color, float* out_depth,
+                         float* out_opacity, int32_t* n_touched, uint32_t* overflow, mgs_timing* timing, void* stream) {
+    if (int rc = mgs_forward_preprocess(cam, P, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                                        geometry, radii, prepare_backward, nullptr, nullptr, nullptr, timing, stream)) return rc;
+    return mgs_forward_render_capacity(cam, P, capacity, geometry, binning, image, out_color, out_depth, out_opacity,
+                                       n_touched, overflow, timing, stream);
 }
 
 int mgs_backward(const mgs_camera* cam, int32_t P, uint64_t R, const float* means3D, const float* shs,

@@ -44,7 +44,7 @@ def forward_tables(rs, means3D, opacities, colors_precomp=None, shs=None, scales
         nr = C.c_uint64(0)
         _lib.check(lib.mgs_forward_preprocess(C.byref(cam), P, _ptr(means3D), _ptr(shs), _ptr(colors_precomp),
                                               _ptr(opacities), _ptr(scales), _ptr(rotations), _ptr(cov3D_precomp),
-                                              geom.data_ptr(), radii.data_ptr(), None, C.byref(nr), None, _stream()),
+                                              geom.data_ptr(), radii.data_ptr(), None, C.byref(nr), None, None, None, _stream()),
                    "mgs_forward_preprocess")
         R = int(nr.value)
         if between is not None:

@@ -36,17 +36,39 @@ class GaussianRasterizationSettings(NamedTuple):
 
 
 # ---- sync-free ("capacity") mode ----------------------------------------------------------------
-# The exact path reads the instance count R back to the host once per forward (as upstream does) to size the
-# binning scratch.  In capacity mode the scratch is sized from the LAST count seen for the same
-# (P, W, H) times a headroom factor, the kernels read the live count on the device, and nothing in
-# forward + backward synchronises the host -- which is what allows a whole tracking / mapping iteration to
-# be captured in a hipGraph (torch.cuda.graph).  An overflow (R > capacity) drops instances and sets a device
-# flag; `check_overflow()` (one sync, e.g. next to the convergence test of the pose step) reports it and raises
-# the capacity so the caller can redo the iteration.
+# The exact path (the default: what an unmodified MonoGS gets) reads the instance count R back to the host once per
+# forward, as upstream does, to size the binning scratch.  It keeps ONE thing between calls: the status word of the last
+# exact forward, which the next forward's count read-back collects at its own synchronisation (`_State.exact_pending`), so
+# that a radix-sort look-back timeout -- the one failure of the exact path -- is raised one forward later instead of never.
+#
+# Capacity mode is opt-in (`set_sync_free(True)`, or implied by a hipGraph capture): the scratch is sized from the LAST count
+# seen for the same (P, W, H) times a headroom factor, the kernels read the live count on the device, and nothing in forward +
+# backward synchronises the host -- which is what lets a whole tracking / mapping iteration be captured in a hipGraph.  An
+# overflow (R > capacity) drops instances and sets a device flag; `check_overflow()` (one sync, e.g. next to the convergence
+# test of the pose step) reports it and raises the capacity so the caller can redo the iteration.  That mode needs memory
+# across calls by construction (the hints); it is bounded: at most HINTS_MAX shapes, at most PENDING_MAX unread flags.
 _sync_free = {"enabled": False, "headroom": 1.5}
-_capacity_hint: dict = {}
-_pending_overflow: list = []
-_graph_overflow: list = []      # flags of forwards recorded inside a hipGraph capture: re-checked on every call
+HINTS_MAX, PENDING_MAX = 64, 1024
+
+
+class _State:
+    capacity_hint: dict = {}
+    pending: list = []            # (key, flag) of capacity-mode forwards not yet checked
+    graph: list = []              # flags of forwards recorded inside a hipGraph capture: re-checked on every call
+    exact_pending = None          # (key, flag) of the last exact forward, or None
+    exact_failed = 0              # status bits collected from earlier exact forwards, raised by the next forward / check
+
+
+_capacity_hint = _State.capacity_hint
+_pending_overflow = _State.pending
+_graph_overflow = _State.graph
+
+
+def _remember_hint(key, R):
+    h = _State.capacity_hint
+    if key not in h and len(h) >= HINTS_MAX:
+        h.pop(next(iter(h)))
+    h[key] = R
 
 
 def set_sync_free(enabled: bool, headroom: float = 1.5):
@@ -56,29 +78,36 @@ def set_sync_free(enabled: bool, headroom: float = 1.5):
 STATUS_CAPACITY_OVERFLOW, STATUS_DEPTH_SORT_TIMEOUT, STATUS_TILE_SORT_TIMEOUT = 1, 2, 4     # MGS_STATUS_* (monogs_raster.h)
 
 
+def _raise_sort_failure(bits):
+    which = [n for b, n in ((STATUS_DEPTH_SORT_TIMEOUT, "depth sort"), (STATUS_TILE_SORT_TIMEOUT, "tile sort")) if bits & b]
+    raise RuntimeError(f"rasteriser: a look-back spin of the {' and the '.join(which)} timed out; "
+                       "the renders since the last check are invalid")
+
+
 def check_overflow() -> bool:
     """Reads the status words of the forwards issued since the last call (synchronises).  True if a capacity-mode
     forward dropped instances -- the capacity hints of the offending shapes are doubled, redo the iteration.  Raises
     if a radix-sort look-back timed out in any forward (exact or capacity mode): its blend order, hence its images
     and gradients, are invalid."""
-    hit, sort_fail = False, 0
-    for key, flag in _pending_overflow + _graph_overflow:
+    hit, sort_fail = False, _State.exact_failed
+    _State.exact_failed = 0
+    todo = _State.pending + _State.graph + ([_State.exact_pending] if _State.exact_pending is not None else [])
+    _State.exact_pending = None
+    for key, flag in todo:
         v = int(flag.item())
         if v & STATUS_CAPACITY_OVERFLOW:
             hit = True
-            _capacity_hint[key] = max(2 * _capacity_hint.get(key, 1), 1024)
+            _remember_hint(key, max(2 * _State.capacity_hint.get(key, 1), 1024))
         sort_fail |= v & (STATUS_DEPTH_SORT_TIMEOUT | STATUS_TILE_SORT_TIMEOUT)
-    _pending_overflow.clear()
+    _State.pending.clear()
     if sort_fail:
-        which = [n for b, n in ((STATUS_DEPTH_SORT_TIMEOUT, "depth sort"), (STATUS_TILE_SORT_TIMEOUT, "tile sort")) if sort_fail & b]
-        raise RuntimeError(f"rasteriser: a look-back spin of the {' and the '.join(which)} timed out; "
-                           "the renders since the last check are invalid")
+        _raise_sort_failure(sort_fail)
     return hit
 
 
 def clear_graph_flags():
     """Forget the overflow flags of captured graphs (call when those graphs are destroyed)."""
-    _graph_overflow.clear()
+    _State.graph.clear()
 
 
 # ---- optional per-stage timing (bench.py) --------------------------------------------------
@@ -99,6 +128,10 @@ def collect_timing():
 
 def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
+
+
+def _al(n: int) -> int:
+    return (int(n) + 255) // 256 * 256
 
 
 def _f32(t: torch.Tensor, name: str) -> torch.Tensor:
@@ -187,60 +220,69 @@ class _RasterizeGaussians(torch.autograd.Function):
             timing = _lib.MgsTiming() if _timing_sink is not None else None
             tref = C.byref(timing) if timing is not None else None
             u8 = dict(dtype=torch.uint8, device=dev)
-            geom = torch.empty(lib.mgs_geometry_bytes(P), **u8)
-            img = torch.empty(lib.mgs_image_bytes(W, H), **u8)
-            radii = torch.empty(P, dtype=torch.int32, device=dev)
-            n_touched = torch.empty(P, dtype=torch.int32, device=dev)
-            color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
-            depth = torch.empty(1, H, W, dtype=torch.float32, device=dev)
-            opacity = torch.empty(1, H, W, dtype=torch.float32, device=dev)
+            # ONE allocation for everything the backward needs back (geometry + image scratch, radii, n_touched and the
+            # scratch of the backward itself) and one for the three images: ten torch.empty per forward were ~35 us of host
+            # time at SLAM sizes.  radii / n_touched / the images are views; the scratch parts travel as raw addresses.
+            want_bwd = P > 0 and any(ctx.needs_input_grad)
+            n_geom, n_img = _al(lib.mgs_geometry_bytes(P)), _al(lib.mgs_image_bytes(W, H))
+            n_ri, n_bwd = _al(4 * P), (_al(lib.mgs_backward_bytes(P)) if want_bwd else 0)
+            arena = torch.empty(n_geom + n_img + 2 * n_ri + n_bwd + 256, **u8)
+            base = arena.data_ptr()
+            off0 = (-base) % 256                                    # the carving functions expect 256-byte-aligned bases
+            geom_p, img_p = base + off0, base + off0 + n_geom
+            o_r = off0 + n_geom + n_img
+            radii = arena[o_r:o_r + 4 * P].view(torch.int32)
+            n_touched = arena[o_r + n_ri:o_r + n_ri + 4 * P].view(torch.int32)
             # The scratch of the backward that will follow is handed to the forward: its per-Gaussian kernel clears the
             # gradient lines of the visible Gaussians (and the pose part) on the way, and the backward starts with no
             # clearing launch and no 64 B x P fill.
-            ctx.scratch = (torch.empty(lib.mgs_backward_bytes(P), **u8)
-                           if (P > 0 and any(ctx.needs_input_grad)) else None)
+            ctx.scratch = arena[o_r + 2 * n_ri:o_r + 2 * n_ri + n_bwd] if want_bwd else None
+            bwd_p = base + o_r + 2 * n_ri if want_bwd else None
             ctx.scratch_used = False
+            out5 = torch.empty(5, H, W, dtype=torch.float32, device=dev)
+            color, depth, opacity = out5[0:3], out5[3:4], out5[4:5]
+            status = torch.empty(1, dtype=torch.int32, device=dev) if P > 0 else None      # this forward's MGS_STATUS_* word
             key = (P, W, H)
             capturing = torch.cuda.is_current_stream_capturing()
-            hint = _capacity_hint.get(key)
+            hint = _State.capacity_hint.get(key)
             if capturing and hint is None:
                 raise RuntimeError("graph capture needs a capacity hint: run one eager forward with the same "
                                    "(P, W, H) first")
+            if _State.exact_failed and not capturing:
+                bits, _State.exact_failed = _State.exact_failed, 0
+                _raise_sort_failure(bits)
             if (capturing or _sync_free["enabled"]) and hint is not None and P > 0:
-                # ---- capacity mode: no read-back, no stream sync
+                # ---- capacity mode: no read-back, no stream sync, one crossing of the FFI boundary
                 R = max(int(hint * _sync_free["headroom"]) + 4096, 4096)
-                _lib.check(lib.mgs_forward_preprocess(
-                    C.byref(cam), P, _ptr(means3D), _ptr(sh_), _ptr(col_), _ptr(opac_), _ptr(sc_), _ptr(rot_),
-                    _ptr(cov_), geom.data_ptr(), radii.data_ptr(), _ptr(ctx.scratch), None, tref, _stream()),
-                    "mgs_forward_preprocess")
                 binning = torch.empty(lib.mgs_binning_bytes(R, W, H), **u8)
-                overflow = torch.empty(1, dtype=torch.int32, device=dev)      # written by the clamp kernel
-                _lib.check(lib.mgs_forward_render_capacity(
-                    C.byref(cam), P, R, geom.data_ptr(), binning.data_ptr(), img.data_ptr(), color.data_ptr(),
-                    depth.data_ptr(), opacity.data_ptr(), n_touched.data_ptr(), overflow.data_ptr(), tref, _stream()),
-                    "mgs_forward_render_capacity")
-                (_graph_overflow if capturing else _pending_overflow).append((key, overflow))
-                if len(_pending_overflow) > 4096:          # nobody is checking: keep the list bounded
-                    del _pending_overflow[:2048]
-                ctx.overflow = overflow
+                _lib.check(lib.mgs_forward_capacity(
+                    C.byref(cam), P, _ptr(means3D), _ptr(sh_), _ptr(col_), _ptr(opac_), _ptr(sc_), _ptr(rot_), _ptr(cov_),
+                    geom_p, radii.data_ptr(), bwd_p, R, binning.data_ptr(), img_p, color.data_ptr(), depth.data_ptr(),
+                    opacity.data_ptr(), n_touched.data_ptr(), status.data_ptr(), tref, _stream()), "mgs_forward_capacity")
+                (_State.graph if capturing else _State.pending).append((key, status))
+                if len(_State.pending) > PENDING_MAX:      # nobody is checking: keep the list bounded
+                    del _State.pending[:PENDING_MAX // 2]
+                ctx.overflow = status
             else:
-                num_rendered = C.c_uint64(0)
+                num_rendered, prev_bits = C.c_uint64(0), C.c_uint32(0)
+                prev = _State.exact_pending
                 _lib.check(lib.mgs_forward_preprocess(
                     C.byref(cam), P, _ptr(means3D), _ptr(sh_), _ptr(col_), _ptr(opac_), _ptr(sc_), _ptr(rot_),
-                    _ptr(cov_), geom.data_ptr(), radii.data_ptr(), _ptr(ctx.scratch), C.byref(num_rendered), tref,
-                    _stream()), "mgs_forward_preprocess")
+                    _ptr(cov_), geom_p, radii.data_ptr(), bwd_p, C.byref(num_rendered),
+                    prev[1].data_ptr() if prev is not None else None, C.byref(prev_bits) if prev is not None else None,
+                    tref, _stream()), "mgs_forward_preprocess")
+                _State.exact_pending = None
+                if prev_bits.value & (STATUS_DEPTH_SORT_TIMEOUT | STATUS_TILE_SORT_TIMEOUT):
+                    _raise_sort_failure(prev_bits.value)       # the PREVIOUS exact forward's sort timed out: never silent
                 R = int(num_rendered.value)
-                _capacity_hint[key] = R
+                _remember_hint(key, R)
                 binning = torch.empty(lib.mgs_binning_bytes(R, W, H), **u8)
-                status = torch.empty(1, dtype=torch.int32, device=dev) if P > 0 else None   # written by duplicate_kernel
                 _lib.check(lib.mgs_forward_render(
-                    C.byref(cam), P, R, geom.data_ptr(), binning.data_ptr(), img.data_ptr(), color.data_ptr(),
+                    C.byref(cam), P, R, geom_p, binning.data_ptr(), img_p, color.data_ptr(),
                     depth.data_ptr(), opacity.data_ptr(), n_touched.data_ptr(), _ptr(status), tref, _stream()),
                     "mgs_forward_render")
                 if status is not None:      # (the depth sort's flag was already checked at the count read-back)
-                    _pending_overflow.append((key, status))
-                    if len(_pending_overflow) > 4096:
-                        del _pending_overflow[:2048]
+                    _State.exact_pending = (key, status)
                 ctx.overflow = None
             if rs.debug:                    # upstream's debug flag: synchronise and check right after the forward
                 check_overflow()
@@ -249,6 +291,8 @@ class _RasterizeGaussians(torch.autograd.Function):
                 d.update(kind="forward", num_rendered=R, P=P)
                 _timing_sink.append(d)
 
+        ctx.cam, ctx.keep = cam, keep          # the backward reuses the camera block (and keeps its tensors alive)
+        ctx.geom_off, ctx.img_off = off0, off0 + n_geom
         ctx.raster_settings = rs
         ctx.num_rendered = R
         ctx.sh_coeffs = M
@@ -258,7 +302,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         dummy = torch.empty(0, device=dev)
         ctx.save_for_backward(means3D, sh_ if sh_ is not None else dummy, col_ if col_ is not None else dummy,
                               opac_, sc_ if sc_ is not None else dummy, rot_ if rot_ is not None else dummy,
-                              cov_ if cov_ is not None else dummy, radii, geom, binning, img)
+                              cov_ if cov_ is not None else dummy, radii, arena, binning)
         ctx.mark_non_differentiable(radii, n_touched)
         ctx.set_materialize_grads(False)     # unused output gradients arrive as None instead of three zero-fill kernels
         return color, radii, depth, opacity, n_touched
@@ -268,7 +312,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         # grad_opacity is ignored, as upstream does
         lib = _lib.load()
         rs = ctx.raster_settings
-        means3D, sh_, col_, opac_, sc_, rot_, cov_, radii, geom, binning, img = ctx.saved_tensors
+        means3D, sh_, col_, opac_, sc_, rot_, cov_, radii, arena, binning = ctx.saved_tensors
+        geom_p, img_p = arena.data_ptr() + ctx.geom_off, arena.data_ptr() + ctx.img_off
         has_sh, has_col, has_sr, has_cov, has_theta, has_rho = ctx.has
         P = means3D.shape[0]
         dev = means3D.device
@@ -276,8 +321,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         need = ctx.needs_input_grad   # means3D, means2D, sh, colors, opacities, scales, rotations, cov3D, theta, rho
 
         with _device_guard(dev):
-            keep = []
-            cam = _camera(rs, ctx.sh_coeffs, keep, ctx.scale_dim)
+            cam = ctx.cam
             f32 = dict(dtype=torch.float32, device=dev)
             g_color = _f32(grad_color, "grad_color") if grad_color is not None else torch.zeros(3, H, W, **f32)
             g_depth = _f32(grad_depth, "grad_depth") if grad_depth is not None else torch.zeros(1, H, W, **f32)
@@ -311,7 +355,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 C.byref(cam), P, ctx.num_rendered,
                 _ptr(means3D), _ptr(sh_) if has_sh else None, _ptr(col_) if has_col else None, _ptr(opac_),
                 _ptr(sc_) if has_sr else None, _ptr(rot_) if has_sr else None, _ptr(cov_) if has_cov else None,
-                radii.data_ptr(), geom.data_ptr(), binning.data_ptr(), img.data_ptr(),
+                radii.data_ptr(), geom_p, binning.data_ptr(), img_p,
                 g_color.data_ptr(), g_depth.data_ptr(),
                 _ptr(d_means2D), _ptr(d_col), _ptr(d_opac), _ptr(d_means3D), _ptr(d_cov), _ptr(d_sh),
                 _ptr(d_scales), _ptr(d_rot), _ptr(d_tau), scratch.data_ptr(), 1 if prepared else 0, tref, _stream()),
@@ -333,13 +377,13 @@ def debug_blend_stats(color: torch.Tensor) -> dict:
     if fn is None or not hasattr(fn, "raster_settings"):
         raise RuntimeError("debug_blend_stats needs the colour image of a differentiable rasteriser forward")
     lib = _lib.load()
-    means3D, _, _, _, _, _, _, _, geom, binning, img = fn.saved_tensors
-    keep = []
-    cam = _camera(fn.raster_settings, fn.sh_coeffs, keep, fn.scale_dim)
+    means3D, _, _, _, _, _, _, _, arena, binning = fn.saved_tensors
+    cam = fn.cam
     out = torch.zeros(8, dtype=torch.int64, device=means3D.device)
     with _device_guard(means3D.device):
-        _lib.check(lib.mgs_debug_blend_stats(C.byref(cam), means3D.shape[0], fn.num_rendered, geom.data_ptr(),
-                                             binning.data_ptr(), img.data_ptr(), out.data_ptr(), _stream()),
+        _lib.check(lib.mgs_debug_blend_stats(C.byref(cam), means3D.shape[0], fn.num_rendered,
+                                             arena.data_ptr() + fn.geom_off, binning.data_ptr(),
+                                             arena.data_ptr() + fn.img_off, out.data_ptr(), _stream()),
                    "mgs_debug_blend_stats")
     v = out.tolist()
     return dict(steps=v[0], survivors=v[1], active_survivors=v[2], active_pairs=v[3], inactive_by_depth_order=v[4],

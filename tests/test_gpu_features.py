@@ -375,6 +375,62 @@ def test_duplicate_emission_paths_agree(native_lib, n, intr):
     assert torch.equal(out[0]["cap"], out[1]["cap"]) and torch.equal(out[0]["cap"], out[0]["color"])
 
 
+def test_exact_path_reports_an_earlier_forwards_status_at_its_own_read_back(native_lib):
+    """The default (exact) path never synchronises for the tile sort's status word: the NEXT exact forward collects it at
+    the count read-back it performs anyway (`mgs_forward_preprocess(prev_status, prev_status_out)`), so a look-back timeout
+    there surfaces one forward later instead of never (debug=False, nobody calling check_overflow)."""
+    from monogs_amd import rasterizer as R
+    from monogs_amd.rasterizer import GaussianRasterizer
+    sc = make_scene(3000, "fr3_office", seed=9)
+    st = _hip_st(sc)
+    dev = lambda t: t.to(DEV)  # noqa: E731
+    args = dict(means3D=dev(sc.means3D), means2D=torch.zeros(3000, 3, device=DEV), opacities=dev(sc.opacities),
+                colors_precomp=dev(sc.colors), scales=dev(sc.scales), rotations=dev(sc.rotations))
+    R.check_overflow()
+    R.set_sync_free(False)
+    ref = GaussianRasterizer(st)(**args)
+    assert R._State.exact_pending is not None and int(R._State.exact_pending[1].item()) == 0
+    R._State.exact_pending[1].fill_(R.STATUS_TILE_SORT_TIMEOUT)      # what ranges_kernel leaves after a timed-out tile sort
+    with pytest.raises(RuntimeError, match="tile sort"):
+        GaussianRasterizer(st)(**args)                                # raised by the next forward, at ITS synchronisation
+    assert R._State.exact_pending is None
+    out = GaussianRasterizer(st)(**args)                              # and only once
+    assert torch.equal(out[0], ref[0])
+    assert not R.check_overflow()
+    # the same word through check_overflow()
+    GaussianRasterizer(st)(**args)
+    R._State.exact_pending[1].fill_(R.STATUS_TILE_SORT_TIMEOUT)
+    with pytest.raises(RuntimeError, match="tile sort"):
+        R.check_overflow()
+    assert not R.check_overflow()
+
+
+def test_c_abi_renders_the_background_for_an_empty_map_in_capacity_mode(native_lib):
+    """P == 0 through the C ABI with geometry == NULL and a non-zero capacity (the binding the reference's FFI would use has
+    no Python guard in front of it): nothing was preprocessed, so nothing may be sorted -- background image, no fault."""
+    import ctypes as C
+    from monogs_amd import _lib
+    from monogs_amd.rasterizer import _camera, _stream
+    lib = _lib.load()
+    sc = make_scene(10, "fr3_office", seed=1, bg=(0.1, 0.2, 0.3))
+    st = _hip_st(sc)
+    keep = []
+    cam = _camera(st, 0, keep, 3)
+    H, W = st.image_height, st.image_width
+    u8 = dict(dtype=torch.uint8, device=DEV)
+    img = torch.empty(lib.mgs_image_bytes(W, H), **u8)
+    binning = torch.empty(lib.mgs_binning_bytes(100000, W, H), **u8)
+    out = torch.full((5, H, W), -1.0, device=DEV)
+    status = torch.full((1,), 77, dtype=torch.int32, device=DEV)
+    for fn, r in ((lib.mgs_forward_render_capacity, 100000), (lib.mgs_forward_render, 0)):
+        out.fill_(-1.0)
+        _lib.check(fn(C.byref(cam), 0, r, None, binning.data_ptr(), img.data_ptr(), out[0:3].data_ptr(), out[3:4].data_ptr(),
+                      out[4:5].data_ptr(), None, status.data_ptr(), None, _stream()), "forward render, P = 0")
+        torch.cuda.synchronize()
+        assert torch.allclose(out[0:3], torch.tensor([0.1, 0.2, 0.3], device=DEV)[:, None, None].expand(3, H, W))
+        assert float(out[3:].abs().max()) == 0.0
+
+
 def test_tile_sort_timeout_raises_its_own_status_bit_and_blends_nothing(native_lib):
     """A look-back timeout in the TILE sort (the depth sort healthy): the status word carries MGS_STATUS_TILE_SORT_TIMEOUT,
     the tile ranges stay empty and nothing is blended -- no instance index is ever read from the half-written list."""

@@ -383,3 +383,159 @@ def run_slam(n_frames=12, intrinsics="fr3_office", tracking_itr_num=100, mapping
                config=dict(tracking_itr_num=tracking_itr_num, mapping_itr_num=mapping_itr_num,
                            window_size=window_size, kf_interval=kf_interval, init_itr_num=init_itr_num))
     return out
+
+
+# ---- the two-process topology of the reference: tracker in the main process, mapper in a spawned one ---------------------
+# (/root/reference/slam.py:102-179: `mp.Process(target=self.mapper.run)`, queues between them; the map crosses the process
+#  boundary on every keyframe -- there as `clone_obj(self.gaussians)` pickled through an mp.Queue,
+#  /root/reference/utils/slam_mapper.py:550-564, here through `MapArena`: two pre-allocated device buffers per tensor shared
+#  once over HIP IPC, a publish = device-to-device copies + a header store, an acquire = views.)
+ARENA_FIELDS = {"xyz": (3,), "rotation": (4,), "scaling": (1,), "opacity": (1,), "rgb": (3,)}
+
+
+class _ArenaMapView:
+    """What the tracker needs of a map, over the views a `MapArena.acquire()` hands out (already activated)."""
+
+    def __init__(self, views):
+        self.get_xyz, self.get_rotation, self.get_scaling = views["xyz"], views["rotation"], views["scaling"]
+        self.get_opacity, self.get_features = views["opacity"], views["rgb"]
+
+
+def _mapper_process(arena, q_in, q_out, cfg):
+    """`Mapper.run` in miniature (/root/reference/utils/slam_mapper.py:566-734): wait for `init` / `keyframe` / `stop`,
+    extend the map from the keyframe, optimise the window, publish the map."""
+    import multiprocessing
+    from .mapping import WindowMapper
+    dev = cfg["device"]
+    torch.cuda.set_device(torch.device(dev))
+    frames, intr = make_sequence(cfg["n_frames"], cfg["intrinsics"], cfg["n_gaussians"], device=dev)
+    bg = torch.zeros(3, device=dev)
+    gmap = GaussianMap(dev)
+    mapper = WindowMapper(gmap, intr, bg, window_size=cfg["window_size"], use_graph=cfg["graph"])
+    mapper.map_surgery = False
+    window: List[Viewpoint] = []
+
+    def publish():
+        with torch.no_grad():
+            return arena.publish({"xyz": gmap.get_xyz, "rotation": gmap.get_rotation, "scaling": gmap.get_scaling,
+                                  "opacity": gmap.get_opacity, "rgb": gmap.get_features})
+    try:
+        while True:
+            msg = q_in.get()
+            if msg[0] == "stop":
+                break
+            tag, idx, R, T = msg
+            vp = frames[idx]
+            vp.update_RT(torch.tensor(R, device=dev), torch.tensor(T, device=dev))
+            t0 = time.perf_counter()
+            if tag == "init":
+                gmap.extend_from_frame(vp, intr, downsample=cfg["init_downsample"], init=True, point_size=1.0)
+                window.append(vp)
+                mapper.initialize_map(vp, iters=cfg["init_itr_num"])
+            else:
+                with torch.no_grad():
+                    pkg = _render(vp, intr, gmap, bg)
+                gmap.extend_from_frame(vp, intr, downsample=cfg["kf_downsample"], render_opacity=pkg["opacity"], point_size=1.0)
+                window.append(vp)
+                if len(window) > cfg["window_size"]:
+                    window.pop(1)
+                mapper.new_keyframe_optimizers(window)
+                mapper.optimize_map(window, iters=cfg["mapping_itr_num"])
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            seq = publish()
+            t2 = time.perf_counter()
+            # (the keyframe's refined pose goes back with the answer, as `sync_backend` carries the keyframes back)
+            q_out.put(("done", idx, seq, len(gmap), t1 - t0, t2 - t1, vp.R.cpu().numpy(), vp.T.cpu().numpy(), len(window)))
+    finally:
+        multiprocessing.current_process()._args = ()       # (a spawned child leaves through os._exit: drop the IPC mappings now)
+        del arena
+        import gc
+        gc.collect()
+        torch.cuda.ipc_collect()
+
+
+def run_slam_two_process(n_frames=12, intrinsics="fr3_office", tracking_itr_num=100, mapping_itr_num=150, window_size=8,
+                         kf_interval=4, init_itr_num=150, n_gaussians=60000, device="cuda:0", capacity=400000, graph=True,
+                         init_downsample=8, kf_downsample=16):
+    """The tracking / mapping loops of `run_slam` split over two processes as the reference runs them, with the map handed
+    over through `MapArena`.  The tracker (this process) tracks every frame against the
+    snapshot it last acquired and, on a keyframe, asks the mapper and waits for the next publish -- the reference's
+    tracker does the same (`utils/slam_tracker.py:362-365`).  Returns rates, the hand-off times and the trajectory error."""
+    import torch.multiprocessing as mp
+
+    from .map_arena import MapArena
+    ctx = mp.get_context("spawn")
+    arena = MapArena(capacity, ARENA_FIELDS, device=device)
+    q_in, q_out = ctx.Queue(), ctx.Queue()
+    cfg = dict(n_frames=n_frames, intrinsics=intrinsics, n_gaussians=n_gaussians, device=device, window_size=window_size,
+               init_itr_num=init_itr_num, mapping_itr_num=mapping_itr_num, graph=graph, init_downsample=init_downsample,
+               kf_downsample=kf_downsample)
+    proc = ctx.Process(target=_mapper_process, args=(arena, q_in, q_out, cfg))
+    proc.start()
+    frames, intr = make_sequence(n_frames, intrinsics, n_gaussians, device=device)
+    bg = torch.zeros(3, device=device)
+    stats = dict(track_s=0.0, track_iters=0, tracked=0, wait_s=0.0, acquire_s=0.0, publish_s=0.0, map_s=0.0, keyframes=0)
+    windows, sizes, seqs = [], [], []
+    tgraph, snapshot, seq = None, None, 0
+    t_all = time.perf_counter()
+
+    def ask(tag, vp):
+        nonlocal snapshot, seq, tgraph
+        t0 = time.perf_counter()
+        q_in.put((tag, vp.frame_idx, vp.R.cpu().numpy(), vp.T.cpu().numpy()))
+        ans = q_out.get(timeout=600)
+        stats["wait_s"] += time.perf_counter() - t0
+        _, idx, new_seq, P, t_map, t_pub, R, T, wlen = ans
+        stats["map_s"] += t_map
+        stats["publish_s"] += t_pub
+        stats["keyframes"] += 1
+        t1 = time.perf_counter()
+        got, views = arena.acquire()
+        stats["acquire_s"] += time.perf_counter() - t1
+        assert got == new_seq and int(views["xyz"].shape[0]) == P, (got, new_seq, P)
+        vp.update_RT(torch.tensor(R, device=device), torch.tensor(T, device=device))
+        if tgraph is not None:
+            tgraph.close()
+            tgraph = None
+        snapshot, seq = _ArenaMapView(views), got
+        windows.append(wlen); sizes.append(P); seqs.append(got)
+    try:
+        for i, vp in enumerate(frames):
+            if i == 0:
+                vp.update_RT(vp.R_gt, vp.T_gt)
+                ask("init", vp)
+                continue
+            prev = frames[i - 1]
+            vp.update_RT(prev.R.clone(), prev.T.clone())
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            if tgraph is None:
+                tgraph = TrackingGraph(vp, intr, snapshot, bg)
+            n_it = tgraph.track(vp, tracking_itr_num)
+            torch.cuda.synchronize(); stats["track_s"] += time.perf_counter() - t0
+            assert not arena.stale(seq), "the mapper overwrote the snapshot the tracker was reading"
+            stats["track_iters"] += n_it
+            stats["tracked"] += 1
+            if i % kf_interval == 0:
+                ask("keyframe", vp)
+    finally:
+        if tgraph is not None:
+            tgraph.close()
+        q_in.put(("stop",))
+        proc.join(timeout=120)
+        snapshot = None
+        del arena
+        import gc
+        for _ in range(5):
+            gc.collect()
+            torch.cuda.ipc_collect()
+            time.sleep(0.05)
+    wall = time.perf_counter() - t_all
+    err = torch.stack([(-(f.R.t() @ f.T) + (f.R_gt.t() @ f.T_gt)).norm() for f in frames[1:]])
+    k = max(stats["keyframes"], 1)
+    return dict(stats, frames=n_frames, wall_s=wall, fps_end_to_end=(n_frames - 1) / wall,
+                tracking_iters_per_s=stats["track_iters"] / max(stats["track_s"], 1e-9),
+                tracking_fps=stats["tracked"] / max(stats["track_s"], 1e-9),
+                handoff_ms=dict(publish=1e3 * stats["publish_s"] / k, acquire=1e3 * stats["acquire_s"] / k),
+                mapper_busy_ms_per_keyframe=1e3 * stats["map_s"] / k, window_sizes=windows, gaussians=sizes, sequences=seqs,
+                ate_rmse_m=float(torch.sqrt((err ** 2).mean())), exitcode=proc.exitcode)

@@ -104,3 +104,18 @@ def test_graph_mapping_runs_clean(native_lib):
     assert r["ate_rmse_m"] < 2e-3
     assert r["mapping_steady_iters_per_s"] and r["mapping_steady_iters_per_s"] > 0
     assert not _r.check_overflow()
+
+
+def test_two_process_run_hands_the_map_over_through_the_arena(native_lib):
+    """The reference's process topology (/root/reference/slam.py:102-179): tracker here, mapper in a spawned process, the
+    map crossing the boundary on every keyframe -- through `MapArena` (device buffers shared once over HIP IPC) instead of
+    `clone_obj` + `mp.Queue` (/root/reference/utils/slam_mapper.py:550-564).  Same trajectory quality as the one-process run;
+    every snapshot the tracker used was consistent."""
+    from monogs_amd.slam_harness import run_slam_two_process
+    r = run_slam_two_process(n_frames=7, intrinsics="fr3_office", tracking_itr_num=100, mapping_itr_num=30, window_size=8,
+                             kf_interval=2, init_itr_num=80, n_gaussians=30000)
+    assert r["exitcode"] == 0
+    assert r["keyframes"] == 4 and r["sequences"] == [1, 2, 3, 4] and r["window_sizes"] == [1, 2, 3, 4]
+    assert r["gaussians"][0] > 1000 and all(b >= a for a, b in zip(r["gaussians"], r["gaussians"][1:]))   # the map only grows
+    assert r["tracked"] == 6 and r["ate_rmse_m"] < 3e-3, r["ate_rmse_m"]
+    assert r["handoff_ms"]["publish"] < 50 and r["handoff_ms"]["acquire"] < 5, r["handoff_ms"]

@@ -706,31 +706,21 @@ __global__ void __launch_bounds__(256) blend_backward_t_kernel(BlendArgs a, int 
         const unsigned long long alive = __builtin_amdgcn_ballot_w64(last >= (uint32_t)b * WAVE + 1u);
         unsigned long long mask = __builtin_amdgcn_ballot_w64(quadrant_hit(c, el, qx0, qy0, alive));
         const uint32_t k_first = (uint32_t)b * WAVE + 1u;          // 1-based list position of instance 0 of this step
-        while (mask) {
-            const int j = 63 - __builtin_clzll(mask);
-            mask &= ~(1ull << j);
-            const uint32_t gid = bcast(gid_l, j);
-            const Rec g = fetch(a, gid);
-            const float dx = g.px - pxf, dy = g.py - pyf;
-            const float power = dx * (g.ca * dx + g.cb * dy) + (g.cc * dy) * dy;
-            const float G = __builtin_amdgcn_exp2f(power);
-            const float alpha = fminf(0.99f, g.op * G);
+        // one survivor: its two per-pixel factors into slot k of the batch (lane = pixel); whose they are -- centre and index
+        // of the Gaussian -- is noted by lane j, which has held all three in registers since it loaded instance j's cull box
+        auto apply = [&](const Rec& g, int j, float power, float G, float alpha) {
             const bool act = (k_first + (uint32_t)j <= last) && !(power > 0.f) && !(alpha < 1.0f / 255.0f);
-            if (__builtin_amdgcn_ballot_w64(act) == 0ull) continue;
+            if (__builtin_amdgcn_ballot_w64(act) == 0ull) return;
             const float a_eff = act ? alpha : 0.f;
             const float inv = __builtin_amdgcn_rcpf(1.f - a_eff);
             const float Tn = T * inv;
-            const float qq = POSE_ONLY ? __builtin_fmaf(g.z, gd, __builtin_fmaf(g.b, g2, __builtin_fmaf(g.g, g1, g.r * g0)))
-                                       : __builtin_fmaf(g.z, gd, __builtin_fmaf(g.b, g2, __builtin_fmaf(g.g, g1, g.r * g0)));
+            const float qq = __builtin_fmaf(g.z, gd, __builtin_fmaf(g.b, g2, __builtin_fmaf(g.g, g1, g.r * g0)));
             const float diff = qq - Bk;
             const float dL_dalpha = diff * Tn + bgT * inv;
             Bk = Bk + a_eff * diff;
             T = Tn;
             const float w = a_eff * Tn;
             const float h = act ? G * dL_dalpha : 0.f;
-            // leave the two factors in the batch's slot (lane = pixel) and remember whose they are
-            // leave the two factors in slot k of the batch (lane = pixel).  Whose they are -- centre and index of the Gaussian --
-            // is noted by lane j, which has held all three in registers since it loaded instance j's cull box.
             fhl[k * WAVE] = h;
             fhl[(BT_SLOTS + k) * WAVE] = w;
             if (__builtin_amdgcn_inverse_ballot_w64(1ull << j)) fmeta[k] = BtMetaRec{c.x, c.y, gid_l};
@@ -738,6 +728,15 @@ __global__ void __launch_bounds__(256) blend_backward_t_kernel(BlendArgs a, int 
                 bt_flush<POSE_ONLY>(bl, BT_SLOTS);
                 k = 0;
             }
+        };
+        while (mask) {
+            const int j = 63 - __builtin_clzll(mask);
+            mask &= ~(1ull << j);
+            const Rec g = fetch(a, bcast(gid_l, j));
+            const float dx = g.px - pxf, dy = g.py - pyf;
+            const float power = dx * (g.ca * dx + g.cb * dy) + (g.cc * dy) * dy;
+            const float G = __builtin_amdgcn_exp2f(power);
+            apply(g, j, power, G, fminf(0.99f, g.op * G));
         }
     }
     if (k) bt_flush<POSE_ONLY>(bl, k);

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define MGS_ABI_VERSION 6
+#define MGS_ABI_VERSION 7
 #define MGS_TILE 16 /* tile edge in pixels; ranges are per 16x16 tile */
 
 /* GaussianRasterizationSettings, minus `prefiltered` / `debug` which are call flags
@@ -136,10 +136,19 @@ int mgs_forward_render(const mgs_camera* cam, int32_t P, uint64_t num_rendered,
 /* Test knob: the bound of the look-back spin (device-wide, all later sorts); 0xFFFFFFFF restores the default. */
 int mgs_debug_set_radix_spin_limit(uint32_t limit);
 /* Test knobs that force an algorithm path whatever the problem size (process-wide; -1 restores the default):
- * "radix_scanned" (0 = one-sweep look-back, 1 = pre-scanned offsets), "scan_small" (0 = the two-launch scan at every size),
+ * "radix_scanned" (0 = one-sweep look-back, 1 = counted tiles), "radix_ballot_rank" (1 = rank with wave ballots instead of
+ * returning LDS atomics: the reference the sort tests compare with), "scan_small" (0 = the two-launch scan at every size),
  * "dup_slot_major" (0 / 1 = the duplicate kernel's emission balanced by Gaussians / by output slots at every size),
  * "knn_grid_min" (Morton-box kNN from this many points).  Nothing on the launch path consults the environment. */
 int mgs_debug_set_option(const char* name, int64_t value);
+
+/* Test entry: the library's stable radix sort of n (key, value) pairs on key bits [0, bits) -- what the forward runs on
+ * the depth keys and on the tile ids -- on caller-provided DEVICE buffers: keys / vals hold the input and receive the
+ * sorted pairs, keys_alt / vals_alt (n words each) are the ping-pong partners, temp (mgs_debug_sort_temp_bytes(n, bits)
+ * bytes) the scratch.  Returns non-zero with mgs_last_error() set if a look-back spin timed out. */
+size_t mgs_debug_sort_temp_bytes(uint64_t n, int32_t bits);
+int mgs_debug_sort_pairs(uint32_t* keys, uint32_t* vals, uint32_t* keys_alt, uint32_t* vals_alt, uint64_t n, int32_t bits,
+                         void* temp, void* stream);
 
 /* Forward, stage 2 without a host-side instance count ("capacity mode"): call mgs_forward_preprocess with
  * num_rendered = NULL (no read-back, no stream sync), size the binning scratch with

@@ -11,7 +11,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MGS_LIB_PATH") or os.path.join(_HERE, "lib", "libmonogs_raster.so")   # (override: kernel experiments)
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 c_float_p = C.c_void_p   # device pointers travel as integers (tensor.data_ptr())
 
@@ -52,6 +52,8 @@ SIGNATURES = {
                            + [C.POINTER(MgsTiming), C.c_void_p]),
     "mgs_debug_set_radix_spin_limit": (C.c_int, [C.c_uint32]),
     "mgs_debug_set_option": (C.c_int, [C.c_char_p, C.c_int64]),
+    "mgs_debug_sort_temp_bytes": (C.c_size_t, [C.c_uint64, C.c_int32]),
+    "mgs_debug_sort_pairs": (C.c_int, [C.c_void_p] * 4 + [C.c_uint64, C.c_int32, C.c_void_p, C.c_void_p]),
     "mgs_forward_render_capacity": (C.c_int, [C.POINTER(MgsCamera), C.c_int32, C.c_uint64] + [C.c_void_p] * 8
                                     + [C.POINTER(MgsTiming), C.c_void_p]),
     "mgs_backward": (C.c_int, [C.POINTER(MgsCamera), C.c_int32, C.c_uint64] + [C.c_void_p] * 7

@@ -349,8 +349,30 @@ int mgs_debug_valu_ceiling(float* out, int32_t iters, void* stream) {
 
 int mgs_debug_set_radix_spin_limit(uint32_t limit) { return set_radix_spin_limit(limit); }
 
+size_t mgs_debug_sort_temp_bytes(uint64_t n, int32_t bits) { return radix_temp_bytes(n, bits); }
+int mgs_debug_sort_pairs(uint32_t* keys, uint32_t* vals, uint32_t* keys_alt, uint32_t* vals_alt, uint64_t n, int32_t bits,
+                         void* temp, void* stream) {
+    if (bits < 1 || bits > 32 || (n && (!keys || !vals || !keys_alt || !vals_alt || !temp))) {
+        set_error("mgs_debug_sort_pairs: bad arguments");
+        return 1;
+    }
+    if (n == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    if (int rc = radix_sort_pairs(keys, vals, keys_alt, vals_alt, n, bits, temp, s)) return rc;
+    if (radix_result_in_b(bits)) {
+        MGS_HIP(hipMemcpyAsync(keys, keys_alt, n * 4, hipMemcpyDeviceToDevice, s));
+        MGS_HIP(hipMemcpyAsync(vals, vals_alt, n * 4, hipMemcpyDeviceToDevice, s));
+    }
+    uint32_t err[RADIX_ERROR_WORDS];
+    MGS_HIP(hipMemcpyAsync(err, radix_error_flag(temp, n, bits), sizeof(err), hipMemcpyDeviceToHost, s));
+    MGS_HIP(hipStreamSynchronize(s));
+    if (err[0] | err[1] | err[2] | err[3]) { set_error("mgs_debug_sort_pairs: a look-back spin timed out"); return 2; }
+    return 0;
+}
+
 int mgs_debug_set_option(const char* name, int64_t value) {
     if (name && !strcmp(name, "radix_scanned")) { g_opt_radix_scanned = (int)value; return 0; }
+    if (name && !strcmp(name, "radix_ballot_rank")) { g_opt_radix_ballot_rank = (int)value; return 0; }
     if (name && !strcmp(name, "dup_slot_major")) { g_opt_dup_slot_major = (int)value; return 0; }
     if (name && !strcmp(name, "blend_bwd_transposed")) { g_opt_blend_bwd_transposed = (int)value; return 0; }
     if (name && !strcmp(name, "scan_small")) { g_opt_scan_small = (int)value; return 0; }

@@ -404,7 +404,7 @@ int launch_depth_sort(const GeometryState& g, int P, hipStream_t s) {
     // the scratch was cleared by preprocess_forward_kernel
     // (the last pass also lays the tile rectangles out in depth order for the scan and duplicate)
     return radix_sort_pairs(g.depth_key, g.iota, g.depth_alt, g.iota_alt, (uint64_t)P, 32, g.sort_temp, s, nullptr, true,
-                            g.rect, g.rect_sorted);
+                            g.rect, g.rect_sorted, nullptr, true);
 }
 
 int launch_sort(const GeometryState& g, const BinningState& b, uint64_t R, int bits, hipStream_t s, const uint32_t* n_dev) {

@@ -218,7 +218,8 @@ void radix_zero_region(void* temp, uint64_t n, int bits, uint32_t** ptr, size_t*
 int radix_sort_pairs(uint32_t* ka, uint32_t* va, uint32_t* kb, uint32_t* vb, uint64_t n, int bits, void* temp,
                      hipStream_t s, const uint32_t* n_dev = nullptr, bool temp_zeroed = false,
                      const uint2* aux_in = nullptr, uint2* aux_out = nullptr,   // last pass also writes aux_out[i] = aux_in[value i]
-                     const uint32_t* ext_hist = nullptr);
+                     const uint32_t* ext_hist = nullptr,
+                     bool aux_empty_for_ones = false);       // a key of all ones gets aux (0, 0) without the fetch
 bool radix_wants_hist(uint64_t n);
 int launch_depth_sort(const GeometryState& g, int P, hipStream_t s);
 int launch_sort(const GeometryState& g, const BinningState& b, uint64_t R, int bits, hipStream_t s,
@@ -226,7 +227,7 @@ int launch_sort(const GeometryState& g, const BinningState& b, uint64_t R, int b
 int launch_ranges(const BinningState& b, uint64_t R, const ImageState& img, int ntiles, int sort_bits, hipStream_t s,
                   const uint32_t* n_dev = nullptr, uint32_t* status = nullptr);
 int set_radix_spin_limit(uint32_t limit);
-extern int g_opt_radix_scanned, g_opt_knn_grid_min, g_opt_scan_small, g_opt_dup_slot_major, g_opt_blend_bwd_transposed;      // test knobs (mgs_debug_set_option)
+extern int g_opt_radix_ballot_rank, g_opt_radix_scanned, g_opt_knn_grid_min, g_opt_scan_small, g_opt_dup_slot_major, g_opt_blend_bwd_transposed;      // test knobs (mgs_debug_set_option)
 int launch_blend_forward(const mgs_camera& cam, const GeometryState& g, const BinningState& b,
                          const ImageState& img, float* out_color, float* out_depth, float* out_opacity,
                          int32_t* n_touched, hipStream_t s);

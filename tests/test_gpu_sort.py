@@ -1,0 +1,84 @@
+"""The hand-written radix sort on its own (pytest -m gpu), through the C ABI's test entry mgs_debug_sort_pairs.
+
+What it replaces is cub::DeviceRadixSort::SortPairs (/root/reference's rasteriser submodule calls
+it on 64-bit (tile | depth) keys): a STABLE sort.  The library ranks a pair inside its wave with one returning LDS atomic
+per item; that is stable only if the LDS unit applies the lanes of one DS instruction to one address in ascending lane
+order, which is what these cases pin: keys with one to five distinct digits (every wave-instruction full of equal
+digits) must come out exactly as torch's stable sort and as the ballot ranking (the first implementation, kept as a
+test knob) put them, on every path (1024 / 2048-pair tiles with look-back, 3072 / 4096-pair counted tiles)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _sort(lib, keys, bits):
+    from monogs_amd._lib import check
+    n = keys.numel()
+    k = keys.clone()
+    v = torch.arange(n, device=DEV, dtype=torch.int32)
+    ka, va = torch.empty_like(k), torch.empty_like(v)
+    temp = torch.empty(lib.mgs_debug_sort_temp_bytes(n, bits), dtype=torch.uint8, device=DEV)
+    check(lib.mgs_debug_sort_pairs(k.data_ptr(), v.data_ptr(), ka.data_ptr(), va.data_ptr(), n, bits, temp.data_ptr(),
+                                   torch.cuda.current_stream().cuda_stream), "mgs_debug_sort_pairs")
+    return k, v
+
+
+def _keys(kind, n, bits, gen):
+    top = (1 << bits) - 1
+    if kind == "uniform":
+        return torch.randint(0, top + 1, (n,), generator=gen, dtype=torch.int64)
+    if kind == "five":          # five distinct keys, two digits each: the adversarial case for the ranking
+        pick = torch.tensor([0, 1, 2, 257, 258]) & top
+        return pick[torch.randint(0, 5, (n,), generator=gen)]
+    if kind == "one":           # every key equal: the sort must be the identity
+        return torch.full((n,), 0x5A5A5A5A & top, dtype=torch.int64)
+    if kind == "sorted":
+        return (torch.arange(n, dtype=torch.int64) * 7919) & top if bits < 20 else torch.arange(n, dtype=torch.int64) & top
+    if kind == "depth":         # float bits of depths in [0.2, 12), a quarter culled (all ones): the forward's first sort
+        z = torch.rand(n, generator=gen) * 11.8 + 0.2
+        k = z.view(torch.int32).long()
+        k[torch.rand(n, generator=gen) < 0.25] = 0xFFFFFFFF
+        return k & top
+    raise ValueError(kind)
+
+
+# sizes that take every kernel configuration: 1024-pair tiles (<= 192 k), 2048-pair (<= 640 k), counted tiles of 4096
+# pairs (one tile per histogram workgroup) and of 3072 pairs (four tiles per histogram workgroup), a ragged last tile each
+@pytest.mark.parametrize("n", [1, 63, 1025, 150_001, 500_003, 1_200_007, 4_300_001])
+@pytest.mark.parametrize("kind,bits", [("uniform", 32), ("five", 16), ("one", 32), ("sorted", 13), ("depth", 32)])
+def test_sort_is_stable_and_matches_torch(native_lib, n, kind, bits):
+    gen = torch.Generator().manual_seed(n * 31 + bits)
+    keys = _keys(kind, n, bits, gen).to(DEV)
+    k32 = keys.to(torch.int32) if bits < 32 else (keys - ((keys >> 31) << 32)).to(torch.int32)     # same bit pattern
+    got_k, got_v = _sort(native_lib, k32, bits)
+    ref_k, ref_v = torch.sort(keys, stable=True)
+    assert torch.equal(got_k.long() & 0xFFFFFFFF, ref_k)
+    assert torch.equal(got_v.long(), ref_v)
+
+
+@pytest.mark.parametrize("n", [150_001, 500_003, 1_200_007, 4_300_001])
+def test_atomic_ranking_equals_ballot_ranking(native_lib, n):
+    gen = torch.Generator().manual_seed(n)
+    keys = _keys("five", n, 16, gen).to(DEV).to(torch.int32)
+    a = _sort(native_lib, keys, 16)
+    native_lib.mgs_debug_set_option(b"radix_ballot_rank", 1)
+    try:
+        b = _sort(native_lib, keys, 16)
+    finally:
+        native_lib.mgs_debug_set_option(b"radix_ballot_rank", 0)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+def test_both_offset_paths_agree_on_a_large_sort(native_lib):
+    gen = torch.Generator().manual_seed(5)
+    keys = _keys("depth", 2_000_000, 32, gen).to(DEV)
+    k32 = (keys - ((keys >> 31) << 32)).to(torch.int32)
+    a = _sort(native_lib, k32, 32)
+    native_lib.mgs_debug_set_option(b"radix_scanned", 0)
+    try:
+        b = _sort(native_lib, k32, 32)
+    finally:
+        native_lib.mgs_debug_set_option(b"radix_scanned", -1)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])

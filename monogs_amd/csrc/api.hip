@@ -31,7 +31,7 @@ GeometryState GeometryState::carve(void* base, int P) {
     g.depth_alt = (uint32_t*)take(p, (size_t)P * sizeof(uint32_t));
     g.iota = (uint32_t*)take(p, (size_t)P * sizeof(uint32_t));
     g.iota_alt = (uint32_t*)take(p, (size_t)P * sizeof(uint32_t));
-    g.perm = radix_result_in_b(32) ? g.iota_alt : g.iota;
+    g.perm = (uint32_t*)take(p, (size_t)P * sizeof(uint32_t));
     g.point_offsets = (uint32_t*)take(p, (size_t)P * sizeof(uint32_t));
     g.scan_blocks = (uint32_t*)take(p, ((size_t)scan_nblocks(P) + 64) * sizeof(uint32_t));
     g.clamped = (uint8_t*)take(p, (size_t)P * 4);
@@ -39,7 +39,7 @@ GeometryState GeometryState::carve(void* base, int P) {
     g.rect_sorted = (uint2*)take(p, (size_t)P * sizeof(uint2));
     g.scan_status = (uint64_t*)take(p, SCAN_SMALL_MAX_BLOCKS * sizeof(uint64_t));
     g.tile_hist = (uint32_t*)take(p, 4 * 256 * sizeof(uint32_t));
-    g.sort_temp_bytes = mgs::sort_temp_bytes((uint64_t)P, 32);
+    g.sort_temp_bytes = radix_depth_temp_bytes((uint64_t)P);
     g.sort_temp = take(p, g.sort_temp_bytes);           // 256-aligned, directly behind tile_hist
     g.end = p;
     return g;
@@ -174,14 +174,14 @@ int mgs_forward_preprocess(const mgs_camera* cam, int32_t P, const float* means3
                                            cov3D_precomp, g, radii,
                                            prepare_backward ? backward_grad_acc(prepare_backward) : nullptr, s)) return rc;
     tm.mark();
-    if (int rc = launch_depth_sort(g, P, s)) return rc;
+    if (int rc = launch_depth_sort(g, P, depth_sort_payload(P, cam->image_width, cam->image_height), s)) return rc;
     tm.mark();
     if (int rc = launch_scan(g, P, s)) return rc;
     tm.mark();
     if (num_rendered) {
         uint32_t total = 0, sort_errors[RADIX_ERROR_WORDS] = {0, 0, 0, 0};
         MGS_HIP(hipMemcpyAsync(&total, g.scan_blocks + scan_nblocks(P), sizeof(uint32_t), hipMemcpyDeviceToHost, s));   // grand total
-        MGS_HIP(hipMemcpyAsync(sort_errors, radix_error_flag(g.sort_temp, (uint64_t)P, 32), sizeof(sort_errors),
+        MGS_HIP(hipMemcpyAsync(sort_errors, radix_depth_error_flag(g.sort_temp, (uint64_t)P), sizeof(sort_errors),
                                hipMemcpyDeviceToHost, s));
         // the status word of an EARLIER forward on this stream rides along: its kernels are done by the time this copy runs,
         // so a tile-sort timeout of the exact path is seen one forward later at no extra synchronisation

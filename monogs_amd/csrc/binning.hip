@@ -142,7 +142,7 @@ int launch_scan(const GeometryState& g, int P, hipStream_t s) {
     const int nb = scan_nblocks(P);
     if (scan_is_small(P)) {
         hipLaunchKernelGGL(scan_small_kernel, dim3(nb), dim3(SCAN_THREADS), 0, s, g.rect_sorted, g.point_offsets, g.scan_blocks,
-                           g.scan_status, P, nb, const_cast<uint32_t*>(radix_error_flag(g.sort_temp, (uint64_t)P, 32)));
+                           g.scan_status, P, nb, const_cast<uint32_t*>(radix_depth_error_flag(g.sort_temp, (uint64_t)P)));
         MGS_HIP(hipGetLastError());
         return 0;
     }
@@ -367,7 +367,7 @@ int g_opt_dup_slot_major = -1;      // mgs_debug_set_option("dup_slot_major", -1
 int launch_duplicate(const mgs_camera& cam, int P, const GeometryState& g, const BinningState& b, uint64_t r_cap,
                      int32_t* n_touched, const ImageState& img, uint64_t sort_n, int sort_bits, uint32_t* count,
                      uint32_t* overflow, hipStream_t s) {
-    const uint32_t* depth_err = P > 0 ? radix_error_flag(g.sort_temp, (uint64_t)P, 32) : nullptr;
+    const uint32_t* depth_err = P > 0 ? radix_depth_error_flag(g.sort_temp, (uint64_t)P) : nullptr;
     const int ntiles = tiles_x(cam.image_width) * tiles_y(cam.image_height);
     int n = P > ntiles ? P : ntiles;
     if (n == 0) return 0;
@@ -400,11 +400,11 @@ int launch_duplicate(const mgs_camera& cam, int P, const GeometryState& g, const
 // ------------------------------------------------------------------------------------------------
 size_t sort_temp_bytes(uint64_t n, int bits) { return radix_temp_bytes(n, bits); }
 
-int launch_depth_sort(const GeometryState& g, int P, hipStream_t s) {
-    // the scratch was cleared by preprocess_forward_kernel
-    // (the last pass also lays the tile rectangles out in depth order for the scan and duplicate)
-    return radix_sort_pairs(g.depth_key, g.iota, g.depth_alt, g.iota_alt, (uint64_t)P, 32, g.sort_temp, s, nullptr, true,
-                            g.rect, g.rect_sorted, nullptr, true);
+int launch_depth_sort(const GeometryState& g, int P, bool payload, hipStream_t s) {
+    // the scratch was cleared by preprocess_forward_kernel; the final pass also lays the tile rectangles out in depth
+    // order for the scan and duplicate (`payload`: they travelled with the pairs, else it gathers them)
+    return radix_sort_depth(g.depth_key, g.depth_alt, g.iota, g.iota_alt, g.rect, payload, g.perm, g.rect_sorted, (uint64_t)P,
+                            g.sort_temp, s, true);
 }
 
 int launch_sort(const GeometryState& g, const BinningState& b, uint64_t R, int bits, hipStream_t s, const uint32_t* n_dev) {

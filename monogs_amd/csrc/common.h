@@ -123,13 +123,15 @@ struct GeometryState {
     float* rec;               // [P][16]
     uint32_t* depth_key;      // [P] float32 bits of the view-space depth (0xFFFFFFFF when culled); sort input
     uint32_t* depth_alt;      // [P] ping-pong partner of depth_key
-    uint32_t* iota;           // [P] 0..P-1; sort input
-    uint32_t* iota_alt;       // [P] ping-pong partner of iota
-    uint32_t* perm;           // = iota or iota_alt: Gaussian index in (depth, index) order -- culled ones last
+    uint32_t* iota;           // [P] ping-pong buffers of the depth sort's values (the first pass takes value = index and
+    uint32_t* iota_alt;       // [P] reads neither)
+    uint32_t* perm;           // [P] Gaussian index in (depth, index) order -- culled ones last: written by the sort's final pass
     uint32_t* point_offsets;  // [P] inclusive scan, in depth order, of the tiles each Gaussian touches (w * h of its rectangle)
     uint32_t* scan_blocks;    // [scan_nblocks(P) + 64]
     uint8_t* clamped;         // [P][4] SH colour clamp flags
-    uint2* rect;              // [P] tile rectangle {x0 | y0 << 16, w | h << 16} (w = h = 0: culled), by Gaussian index
+    uint2* rect;              // [P] tile rectangle {x0 | y0 << 16, w | h << 16} (w = h = 0: culled), by Gaussian index; or
+                              //     (depth_sort_payload()) uint32[2 P]: the first half x0 | y0 << 8 | w << 16 | h << 24,
+                              //     which the depth sort carries along as a payload, the second half its ping-pong partner
     uint2* rect_sorted;       // [P] the same in depth order: written by the last pass of the depth sort, so that the
                               //     scan and duplicate read it coalesced instead of gathering through perm[]
     uint64_t* scan_status;    // [SCAN_SMALL_MAX_BLOCKS] block totals of the single-launch scan (zeroed by preprocess)
@@ -208,11 +210,14 @@ int launch_duplicate(const mgs_camera& cam, int P, const GeometryState& g, const
                      uint32_t* overflow, hipStream_t s);
 size_t sort_temp_bytes(uint64_t n, int bits);
 size_t radix_temp_bytes(uint64_t n, int bits);
+size_t radix_depth_temp_bytes(uint64_t n);
 bool radix_result_in_b(int bits);
 constexpr int RADIX_ERROR_WORDS = 4;      // = RS_MAX_PASSES (radix_sort.hip)
 const uint32_t* radix_error_flag(void* temp, uint64_t n, int bits);
+const uint32_t* radix_depth_error_flag(void* temp, uint64_t n);
 __device__ __forceinline__ uint32_t radix_failed(const uint32_t* __restrict__ e) { return (e[0] | e[1]) | (e[2] | e[3]); }
 void radix_zero_region(void* temp, uint64_t n, int bits, uint32_t** ptr, size_t* words);   // what must be 0 before a sort
+void radix_depth_zero_region(void* temp, uint64_t n, uint32_t** ptr, size_t* words);
 // `ext_hist` ([4][256], one-sweep path only): digit counts of the keys already counted by the kernel that produced them
 // -- the sort then launches no histogram kernel.  radix_wants_hist(n) tells the producer whether they will be used.
 int radix_sort_pairs(uint32_t* ka, uint32_t* va, uint32_t* kb, uint32_t* vb, uint64_t n, int bits, void* temp,
@@ -221,7 +226,14 @@ int radix_sort_pairs(uint32_t* ka, uint32_t* va, uint32_t* kb, uint32_t* vb, uin
                      const uint32_t* ext_hist = nullptr,
                      bool aux_empty_for_ones = false);       // a key of all ones gets aux (0, 0) without the fetch
 bool radix_wants_hist(uint64_t n);
-int launch_depth_sort(const GeometryState& g, int P, hipStream_t s);
+// The forward's first sort (radix_sort.hip): depth keys -> perm + rect_sorted; three 9-bit passes (+ a fourth that only
+// runs for depths beyond 13 107 units).  radix_depth_payload(n): the sort carries the packed rectangles itself.
+bool radix_depth_payload(uint64_t n);
+int radix_sort_depth(uint32_t* keys, uint32_t* key_b, uint32_t* val_a, uint32_t* val_b, void* rect, bool payload,
+                     uint32_t* perm, uint2* rect_sorted, uint64_t n, void* temp, hipStream_t s, bool temp_zeroed);
+// the packed form needs both tile-grid dimensions to fit a byte
+inline bool depth_sort_payload(int P, int W, int H) { return radix_depth_payload((uint64_t)P) && tiles_x(W) <= 255 && tiles_y(H) <= 255; }
+int launch_depth_sort(const GeometryState& g, int P, bool payload, hipStream_t s);
 int launch_sort(const GeometryState& g, const BinningState& b, uint64_t R, int bits, hipStream_t s,
                 const uint32_t* n_dev = nullptr);
 int launch_ranges(const BinningState& b, uint64_t R, const ImageState& img, int ntiles, int sort_bits, hipStream_t s,

@@ -164,7 +164,7 @@ struct PreArgs {
     const float *V, *PM, *campos;
     float* rec;
     uint32_t* depth_key;
-    uint32_t* iota;
+    int rect_packed;          // rect is uint32[P]: x0 | y0 << 8 | w << 16 | h << 24
     uint8_t* clamped;
     uint2* rect;
     int32_t* radii;
@@ -321,9 +321,13 @@ __global__ void __launch_bounds__(256) preprocess_forward_kernel(PreArgs a) {
     const bool vis = preprocess_one<COV, PRECOMP>(a, c, idx, x, y, z, cov_in, s, q, col_in, opac, o);
     // ---- every output written once (culled Gaussians: radius 0, empty rectangle, key behind every visible one)
     a.radii[idx] = vis ? o.radius : 0;
-    a.rect[idx] = vis ? o.rect : make_uint2(0u, 0u);
+    if (a.rect_packed) {       // (large maps on grids of <= 255 x 255 tiles: the depth sort carries this word with the pair)
+        const uint32_t r4 = (o.rect.x & 0xFFu) | ((o.rect.x >> 16) << 8) | ((o.rect.y & 0xFFu) << 16) | ((o.rect.y >> 16) << 24);
+        reinterpret_cast<uint32_t*>(a.rect)[idx] = vis ? r4 : 0u;
+    } else {
+        a.rect[idx] = vis ? o.rect : make_uint2(0u, 0u);
+    }
     a.depth_key[idx] = vis ? o.key : 0xFFFFFFFFu;
-    a.iota[idx] = (uint32_t)idx;
     if (vis) {
         float4* rec = reinterpret_cast<float4*>(a.rec + (size_t)idx * REC_FLOATS);
         rec[0] = o.r0; rec[1] = o.r1; rec[2] = o.r2; rec[3] = o.r3;
@@ -356,7 +360,7 @@ int launch_preprocess_forward(const mgs_camera& cam, int P, const float* means3D
     a.means3D = means3D; a.shs = shs; a.colors = colors_precomp; a.opacities = opacities;
     a.scales = scales; a.rotations = rotations; a.cov3D = cov3D_precomp;
     a.V = cam.viewmatrix; a.PM = cam.projmatrix; a.campos = cam.campos;
-    a.rec = g.rec; a.depth_key = g.depth_key; a.iota = g.iota;
+    a.rec = g.rec; a.depth_key = g.depth_key;
     a.grad_acc = prepare_grad_acc;
     a.rot_aligned16 = rotations && ((size_t)rotations % 16 == 0);
     a.clamped = g.clamped; a.rect = g.rect; a.radii = radii;
@@ -368,7 +372,8 @@ int launch_preprocess_forward(const mgs_camera& cam, int P, const float* means3D
     a.P = P; a.W = cam.image_width; a.H = cam.image_height;
     a.gx = tiles_x(a.W); a.gy = tiles_y(a.H); a.deg = cam.sh_degree; a.M = cam.sh_coeffs;
     if (P == 0) return 0;
-    radix_zero_region(g.sort_temp, (uint64_t)P, 32, &a.zero_ptr, &a.zero_words);
+    a.rect_packed = depth_sort_payload(P, cam.image_width, cam.image_height) ? 1 : 0;
+    radix_depth_zero_region(g.sort_temp, (uint64_t)P, &a.zero_ptr, &a.zero_words);
     // + the two small tables carved right in front of it (scan status words, tile-sort digit counts)
     a.zero_words += (size_t)((char*)a.zero_ptr - (char*)g.scan_status) / 4;
     a.zero_ptr = (uint32_t*)g.scan_status;

@@ -74,12 +74,15 @@ def forward_tables(rs, means3D, opacities, colors_precomp=None, shs=None, scales
     point_list = view(binning, (3 if in_b else 2) * _au(r * 4), R * 4, torch.int32)
     rec = view(geom, 0, P * 64, torch.float32).reshape(P, 16)
     o = _au(P * 64)
-    # geometry scratch after rec (GeometryState::carve, csrc/api.hip): depth_key, depth_alt, iota, iota_alt (4 passes: result
-    # back in iota), point_offsets, scan_blocks, clamped, rect {x0 | y0 << 16, w | h << 16}
-    perm = view(geom, o + 2 * _au(P * 4), P * 4, torch.int32)
-    o_rect = o + 5 * _au(P * 4) + _au(((P + 2047) // 2048 + 64) * 4) + _au(P * 4)
-    wh = view(geom, o_rect, P * 8, torch.int32).reshape(P, 2)[:, 1]
-    tiles_touched = (wh & 0xFFFF) * ((wh >> 16) & 0xFFFF)           # tiles each Gaussian touches = w * h of its rectangle
+    # geometry scratch after rec (GeometryState::carve, csrc/api.hip): depth_key, depth_alt, iota, iota_alt (the depth
+    # sort's ping-pong buffers), perm (its result), point_offsets, scan_blocks, clamped, rect (by Gaussian index: consumed
+    # by the sort, possibly as its packed payload), rect_sorted {x0 | y0 << 16, w | h << 16} in depth order
+    perm = view(geom, o + 4 * _au(P * 4), P * 4, torch.int32)
+    o_rect = o + 6 * _au(P * 4) + _au(((P + 2047) // 2048 + 64) * 4) + _au(P * 4)
+    wh_sorted = view(geom, o_rect + _au(P * 8), P * 8, torch.int32).reshape(P, 2)[:, 1]
+    tiles_touched = torch.zeros(P, dtype=torch.int32, device=geom.device)
+    # tiles each Gaussian touches = w * h of its rectangle (scattered back from depth order to Gaussian index)
+    tiles_touched[perm.long()] = (wh_sorted & 0xFFFF) * ((wh_sorted >> 16) & 0xFFFF)
     depth_key = rec[:, 11].contiguous().view(torch.int32)          # float32 bits of the view-space depth
     return dict(color=color, depth=depth, opacity=opacity, radii=radii, n_touched=n_touched, num_rendered=R,
                 status=int(status.item()),

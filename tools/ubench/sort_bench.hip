@@ -30,7 +30,8 @@ void set_error(const char* fmt, ...) {
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
 int main(int argc, char** argv) {
-    const bool depth = argc < 2 || !strcmp(argv[1], "depth");
+    const bool far = argc > 1 && !strcmp(argv[1], "depthfar");      // depth keys, a few of them beyond 13 107 units: the fourth pass runs
+    const bool depth = argc < 2 || !strcmp(argv[1], "depth") || far;
     mgs::g_opt_radix_ballot_rank = argc > 2 ? atoi(argv[2]) : 0;
     mgs::g_opt_radix_scanned = argc > 4 ? atoi(argv[4]) : -1;
     const uint64_t n = argc > 3 && atoll(argv[3]) > 0 ? strtoull(argv[3], nullptr, 10) : (depth ? 2000000ull : 5271297ull);
@@ -43,12 +44,13 @@ int main(int argc, char** argv) {
         std::uniform_real_distribution<float> z(0.2f, 12.0f), u(0.f, 1.f);
         for (uint64_t i = 0; i < n; ++i) {
             float d = z(rng);
+            if (far && (i % 1000) == 7) d *= 5000.f;
             uint32_t b;
             memcpy(&b, &d, 4);
             const bool culled = u(rng) < 0.23f;
             keys[i] = culled ? 0xFFFFFFFFu : b;
             vals[i] = (uint32_t)i;
-            aux[i] = culled ? make_uint2(0u, 0u) : make_uint2((uint32_t)i * 7u, (uint32_t)i ^ 0x5555u);
+            aux[i] = culled ? make_uint2(0u, 0u) : make_uint2((uint32_t)(i % 120) | ((uint32_t)(i % 67) << 16), (uint32_t)(1 + i % 5) | ((uint32_t)(1 + i % 3) << 16));
         }
     } else if (few) {
         const uint32_t pick[5] = {0u, 1u, 2u, 257u, 258u};
@@ -70,13 +72,17 @@ int main(int argc, char** argv) {
             ++gi;
         }
     }
-    uint32_t *ka, *va, *kb, *vb;
+    uint32_t *ka, *va, *kb, *vb, *perm;
     uint2 *aux_in, *aux_out;
     void* temp;
-    const size_t tb = mgs::radix_temp_bytes(n, bits);
+    const bool payload = depth && mgs::radix_depth_payload(n);
+    const size_t tb = depth ? mgs::radix_depth_temp_bytes(n) : mgs::radix_temp_bytes(n, bits);
+    CK(hipMalloc(&perm, n * 4));
     CK(hipMalloc(&ka, n * 4)); CK(hipMalloc(&va, n * 4)); CK(hipMalloc(&kb, n * 4)); CK(hipMalloc(&vb, n * 4));
     CK(hipMalloc(&aux_in, n * 8)); CK(hipMalloc(&aux_out, n * 8)); CK(hipMalloc(&temp, tb));
-    CK(hipMemcpy(aux_in, aux.data(), n * 8, hipMemcpyHostToDevice));
+    std::vector<uint32_t> packed(n);
+    for (uint64_t i = 0; i < n; ++i)
+        packed[i] = (aux[i].x & 0xFFu) | ((aux[i].x >> 16) << 8) | ((aux[i].y & 0xFFu) << 16) | ((aux[i].y >> 16) << 24);
     const uint32_t tiles = mgs::rs_tiles(n);
     uint64_t* trace;
     CK(hipMalloc(&trace, (size_t)tiles * 8 * 8));
@@ -85,10 +91,12 @@ int main(int argc, char** argv) {
     auto upload = [&]() {
         (void)hipMemcpyAsync(ka, keys.data(), n * 4, hipMemcpyHostToDevice, s);
         (void)hipMemcpyAsync(va, vals.data(), n * 4, hipMemcpyHostToDevice, s);
+        if (payload) (void)hipMemcpyAsync(aux_in, packed.data(), n * 4, hipMemcpyHostToDevice, s);     // (the sort consumes it)
+        else if (depth) (void)hipMemcpyAsync(aux_in, aux.data(), n * 8, hipMemcpyHostToDevice, s);
     };
     auto sort = [&]() {
-        return mgs::radix_sort_pairs(ka, va, kb, vb, n, bits, temp, s, nullptr, false, depth ? aux_in : nullptr,
-                                     depth ? aux_out : nullptr, nullptr, depth);
+        if (depth) return mgs::radix_sort_depth(ka, kb, va, vb, aux_in, payload, perm, aux_out, n, temp, s, false);
+        return mgs::radix_sort_pairs(ka, va, kb, vb, n, bits, temp, s, nullptr, false, nullptr, nullptr, nullptr, false);
     };
     // ---- correctness against std::stable_sort
     upload();
@@ -96,19 +104,19 @@ int main(int argc, char** argv) {
     CK(hipStreamSynchronize(s));
     const bool in_b = mgs::radix_result_in_b(bits);
     std::vector<uint32_t> gk(n), gv(n);
-    CK(hipMemcpy(gk.data(), in_b ? kb : ka, n * 4, hipMemcpyDeviceToHost));
-    CK(hipMemcpy(gv.data(), in_b ? vb : va, n * 4, hipMemcpyDeviceToHost));
+    if (!depth) CK(hipMemcpy(gk.data(), in_b ? kb : ka, n * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(gv.data(), depth ? perm : (in_b ? vb : va), n * 4, hipMemcpyDeviceToHost));
     std::vector<uint32_t> order(n);
     std::iota(order.begin(), order.end(), 0u);
     std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return keys[a] < keys[b]; });
     uint64_t bad = 0;
-    for (uint64_t i = 0; i < n; ++i) bad += (gk[i] != keys[order[i]]) || (gv[i] != vals[order[i]]);
+    for (uint64_t i = 0; i < n; ++i) bad += (!depth && gk[i] != keys[order[i]]) || (gv[i] != vals[order[i]]);
     if (depth) {
         std::vector<uint2> ga(n);
         CK(hipMemcpy(ga.data(), aux_out, n * 8, hipMemcpyDeviceToHost));
         for (uint64_t i = 0; i < n; ++i) bad += ga[i].x != aux[order[i]].x || ga[i].y != aux[order[i]].y;
     }
-    printf("%s sort of %llu pairs, %s ranking, %s: %u tiles, %s\n", depth ? "depth" : (few ? "few-keys" : "tile"), (unsigned long long)n,
+    printf("%s sort of %llu pairs, %s ranking, %s: %u tiles, %s\n", depth ? (far ? "depth (some beyond the narrow range)" : (payload ? "depth (payload)" : "depth (gather)")) : (few ? "few-keys" : "tile"), (unsigned long long)n,
            mgs::g_opt_radix_ballot_rank ? "ballot" : "LDS-atomic", mgs::rs_scanned(n) ? "counted tiles" : "one sweep", tiles, bad ? "WRONG" : "matches std::stable_sort");
     if (bad) return 2;
     // ---- time (the input of an even/odd pass count ends where it started or not: re-upload outside the timed region is
@@ -140,6 +148,7 @@ int main(int argc, char** argv) {
         upload();
         CK(hipMemsetAsync(trace, 0, (size_t)tiles * 64, s));
         CK(hipMemsetAsync(htrace, 0, (size_t)tiles * 32, s));
+        if (which == 1 && depth) break;     // (the depth plan has no one-pass form)
         int rc = which == 0 ? sort()
                             : mgs::radix_sort_pairs(ka, va, kb, vb, n, 8, temp, s, nullptr, false, nullptr, nullptr, nullptr, false);
         if (rc) return 1;

@@ -82,3 +82,35 @@ def test_both_offset_paths_agree_on_a_large_sort(native_lib):
     finally:
         native_lib.mgs_debug_set_option(b"radix_scanned", -1)
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+def test_depths_beyond_the_narrow_range_take_the_fourth_pass(native_lib):
+    """Large maps sort bits(depth) - bits(0.2) in three 9-bit passes, exact up to depth 13 107; beyond, a device flag
+    turns the always-launched fourth pass on.  A scene scaled by 4000 (same image up to the near cull, depths 2 000 -
+    34 000) must give the tile lists of the plain four-pass sort (the one-sweep path) bit for bit, sorted by
+    (tile, depth bits, index)."""
+    from monogs_amd.debug import forward_tables
+    from monogs_amd.rasterizer import GaussianRasterizationSettings
+    from monogs_amd.synthetic import make_scene, scene_settings
+    K = 4000.0
+    sc = make_scene(700_000, "fr3_office", seed=11, near_fraction=0.0)
+    sc = sc._replace(means3D=sc.means3D * K, scales=sc.scales * K, t=sc.t * K)
+    st = scene_settings(sc, GaussianRasterizationSettings, device=DEV)
+    dev = lambda x: x.to(DEV)  # noqa: E731
+    args = dict(colors_precomp=dev(sc.colors), scales=dev(sc.scales.repeat(1, 3)), rotations=dev(sc.rotations))
+    t = forward_tables(st, dev(sc.means3D), dev(sc.opacities), **args)
+    assert t["status"] == 0 and t["num_rendered"] > 0
+    vis = t["radii"] > 0
+    depth = t["rec"][:, 11]
+    assert float(depth[vis].max()) > 13107.2 > float(depth[vis].min())          # both sides of the narrow range
+    pl = t["point_list"].long()
+    key = (t["tile_sorted"].long() << 32) | (t["depth_key"].long() & 0xFFFFFFFF)[pl]
+    d = key[1:] - key[:-1]
+    assert bool((d >= 0).all()) and bool((pl[1:][d == 0] > pl[:-1][d == 0]).all())
+    native_lib.mgs_debug_set_option(b"radix_scanned", 0)
+    try:
+        t2 = forward_tables(st, dev(sc.means3D), dev(sc.opacities), **args)
+    finally:
+        native_lib.mgs_debug_set_option(b"radix_scanned", -1)
+    assert torch.equal(t["point_list"], t2["point_list"]) and torch.equal(t["ranges"], t2["ranges"])
+    assert torch.equal(t["perm"], t2["perm"]) and torch.equal(t["color"], t2["color"])

@@ -90,12 +90,12 @@ constexpr uint64_t RS_COUNT_MASK = (1ull << 62) - 1;
 constexpr uint32_t RS_SPIN_LIMIT = 1u << 22;
 // the bound actually used by the look-back spin: a device word so that a test can shrink it (mgs_debug_set_radix_spin_limit)
 __device__ uint32_t g_rs_spin_limit = RS_SPIN_LIMIT;
-// predecessor status words fetched per look-back step and digit.  (Measured, round 2: wider windows for the small sorts --
-// 64 words for the 40-tile depth sort of a 40 k map, 32 for the 200-tile tile sort -- on the theory that the look-back is a
-// chain of round trips: 12.5-14 us per pass instead of 9.2-10.7, 15.6-16.3 instead of 14.1-14.3.  Most predecessors have
-// already published their inclusive count when a tile looks back; the extra loads and the longer consume loop only cost.
-//  Narrower windows, 8 and 4 words: 52.9 / 53.4 us against 56.2 us for the depth sort at 100 k -- inside the noise.)
-constexpr int RS_WINDOW = 16;
+// (The first one-sweep version looked back 16 predecessors at a time for a tile with an inclusive count.  Round 2 tried
+//  wider windows -- 64 words for the 40-tile depth sort of a 40 k map, 32 for the 200-tile tile sort: 12.5-14 us per pass
+//  instead of 9.2-10.7, 15.6-16.3 instead of 14.1-14.3 -- and narrower ones, inside the noise.  Round 3 replaced the walk
+//  by the two-level all-gather in rs_pass_kernel: depth sort of 40 k keys 55.5 -> 45.8 us, tile sort of 415 k instances
+//  51.1 -> 38.1 us.)
+constexpr uint32_t RS_GROUP = 16;                  // tiles per group of the one-sweep all-gather
 
 // depth keys: see the header.  key - RS_DEPTH_SUB < RS_DEPTH_NARROW for every visible depth below 13 107.2
 constexpr uint32_t RS_DEPTH_SUB = 0x3E4CCCCDu;             // float bits of 0.2f (preprocess culls depth <= 0.2)
@@ -187,6 +187,8 @@ static inline RsTree rs_tree(uint32_t tiles) {
 //   one sweep:     [status: passes * tiles * radix u64]
 //   counted tiles: [sums: passes * (rows of tree levels >= 1) * radix u32][counts: tiles * radix u32 (rewritten by
 //                  every pass, never cleared)]
+// one sweep: status rows of a pass = one per tile + one per group of RS_GROUP tiles
+static inline size_t rs_status_rows(uint32_t tiles) { return (size_t)tiles + (tiles + RS_GROUP - 1) / RS_GROUP; }
 struct RsTemp {
     uint32_t* hist;
     uint32_t* tickets;
@@ -216,7 +218,7 @@ static RsTemp rs_carve(void* temp, uint64_t n, const RsPlan& pl, bool scanned) {
         t.bytes = t.zero_bytes + (size_t)tiles * pl.radix * sizeof(uint32_t);
     } else {
         t.counts = nullptr;
-        t.zero_bytes = (size_t)(q - p) + (size_t)pl.npasses * tiles * pl.radix * sizeof(uint64_t);
+        t.zero_bytes = (size_t)(q - p) + (size_t)pl.npasses * rs_status_rows(tiles) * pl.radix * sizeof(uint64_t);
         t.bytes = t.zero_bytes;
     }
     return t;
@@ -399,7 +401,8 @@ struct RsPassArgs {
     int shift;
     uint32_t sub;
     const uint32_t* hist;     // one sweep: [radix] global count of each digit for this pass
-    uint64_t* status;         // one sweep: [tiles][radix]
+    uint64_t* status;         // one sweep: [tiles + groups][radix]
+    uint32_t tiles;
     uint32_t* ticket;
     uint32_t* error;          // [RS_MAX_PASSES] one word per pass: pass p raises error[p] when a look-back spin times out
     int pass;
@@ -435,7 +438,6 @@ template <int ITEMS, int DB, bool SCANNED, bool PAYLOAD, bool BALLOT, bool VIDX>
 __global__ void __launch_bounds__(RS_THREADS, (SCANNED && ITEMS == RS_ITEMS_WIDE && DB == 8 && !PAYLOAD) ? 7 : 1) rs_pass_kernel(RsPassArgs a) {
     constexpr int TILE_PAIRS = RS_THREADS * ITEMS;
     constexpr int RADIX = 1 << DB, DPT = RADIX / RS_THREADS;
-    constexpr int WINDOW = RS_WINDOW / DPT;
     constexpr int SBUF = (SCANNED && 2 * RS_WAVES * RADIX > TILE_PAIRS) ? 2 * RS_WAVES * RADIX : TILE_PAIRS;
     __shared__ uint32_t wave_hist[RS_WAVES][RADIX];
     __shared__ uint32_t digit_base[RADIX];
@@ -637,78 +639,72 @@ __global__ void __launch_bounds__(RS_THREADS, (SCANNED && ITEMS == RS_ITEMS_WIDE
 #pragma unroll
         for (int j = 0; j < DPT; ++j) { gdigit_base[j] = run; run += hcount[j]; }
     }
-    if (SCANNED) {
+    if constexpr (SCANNED) {
 #pragma unroll
         for (int j = 0; j < DPT; ++j) gbase[t * DPT + j] = gdigit_base[j] + before[j] - dbase[j];
         __syncthreads();
     } else {
-        // ---- publish, look back, publish (the thread's digits side by side)
-        uint64_t* my = a.status + (size_t)tile * RADIX + t * DPT;
-        uint64_t prefix[DPT];
+        // ---- publish, gather, publish: a two-level all-gather of the tiles' digit counts (one digit per thread).
+        // Every tile publishes its counts; it reads the counts of the <= 15 tiles before it in its group of 16 in ONE
+        // batch of loads; the last tile of a group publishes the group's sum; every tile reads the sums of the groups
+        // before its own, 16 per batch.  Two dependent round trips whatever the number of tiles.  (The first version
+        // walked back 16 predecessors at a time until it met a tile that had already published an INCLUSIVE count: with
+        // every tile of a small sort starting together nobody has one early, and tile T paid ~T/16 dependent round
+        // trips -- 4.4 us of a tile's 9.8 us at 40 tiles, 7.7 of 12 us at 203, tools/ubench/sort_bench.)
+        // A tile only waits for tiles with a smaller ticket, which have started; the spins are bounded.
+        static_assert(DPT == 1, "the one-sweep path ranks 256 digits");
+        constexpr uint32_t G = RS_GROUP;
+        const uint32_t grp = tile / G, jin = tile % G;                  // wave-uniform
+        uint64_t* gstat = a.status + (size_t)a.tiles * RADIX;           // the group words follow the tiles' words
+        __hip_atomic_store(a.status + (size_t)tile * RADIX + t, RS_FLAG_LOCAL | (uint64_t)total[0], __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t spins = 0;
+        bool gave_up = false;
+        uint32_t pre = 0;
+        if (jin > 0) {
+            const uint64_t* row = a.status + (size_t)grp * G * RADIX + t;
+            uint64_t w[G - 1];
+            bool all;
+            do {
 #pragma unroll
-        for (int j = 0; j < DPT; ++j) prefix[j] = 0;
-        if (tile == 0) {
-#pragma unroll
-            for (int j = 0; j < DPT; ++j)
-                __hip_atomic_store(my + j, RS_FLAG_GLOBAL | (uint64_t)total[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-#pragma unroll
-            for (int j = 0; j < DPT; ++j)
-                __hip_atomic_store(my + j, RS_FLAG_LOCAL | (uint64_t)total[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            // Batched look-back: WINDOW predecessor words per digit are requested at once (independent loads, one
-            // memory latency), then consumed nearest-first.  With every resident tile starting together the
-            // serial walk costs ~sqrt(2*tiles) dependent round trips; the window divides that by WINDOW.
-            int64_t jp[DPT];
-            bool found[DPT];
-#pragma unroll
-            for (int j = 0; j < DPT; ++j) { jp[j] = (int64_t)tile - 1; found[j] = false; }
-            uint32_t spins = 0;
-            bool all = false, gave_up = false;
-            while (!all && !gave_up) {
-                uint64_t w[DPT][WINDOW];
-#pragma unroll
-                for (int j = 0; j < DPT; ++j)
-#pragma unroll
-                    for (int q = 0; q < WINDOW; ++q) {
-                        const int64_t jj = jp[j] - q;
-                        w[j][q] = (jj >= 0 && !found[j])
-                                      ? __hip_atomic_load(a.status + (size_t)jj * RADIX + t * DPT + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                      : RS_FLAG_GLOBAL;              // virtual tile -1: inclusive count 0
-                    }
+                for (uint32_t q = 0; q < G - 1; ++q)
+                    w[q] = q < jin ? __hip_atomic_load(row + (size_t)q * RADIX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : RS_FLAG_LOCAL;
                 all = true;
-                bool stuck = false;
 #pragma unroll
-                for (int j = 0; j < DPT; ++j) {
-                    int used = 0;
-#pragma unroll
-                    for (int q = 0; q < WINDOW; ++q) {
-                        if (!found[j] && used == q) {
-                            const uint64_t f = w[j][q] >> 62;
-                            if (f != 0ull) {
-                                prefix[j] += w[j][q] & RS_COUNT_MASK;
-                                ++used;
-                                found[j] = (f != 1ull);
-                            }
-                        }
-                    }
-                    jp[j] -= used;
-                    stuck |= !found[j] && used == 0;                 // nearest predecessor not published yet
-                    all &= found[j];
-                }
-                if (stuck) {
-                    if (++spins > g_rs_spin_limit) {
-                        atomicExch(a.error + a.pass, 1u);
-                        gave_up = true;
-                    }
+                for (uint32_t q = 0; q < G - 1; ++q) all &= (w[q] >> 62) != 0ull;
+                if (!all) {
+                    if (++spins > g_rs_spin_limit) { atomicExch(a.error + a.pass, 1u); gave_up = true; }
                     __builtin_amdgcn_s_sleep(1);
                 }
-            }
+            } while (!all && !gave_up);
 #pragma unroll
-            for (int j = 0; j < DPT; ++j)
-                __hip_atomic_store(my + j, RS_FLAG_GLOBAL | (prefix[j] + (uint64_t)total[j]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (uint32_t q = 0; q < G - 1; ++q) pre += (uint32_t)(w[q] & RS_COUNT_MASK);
         }
+        if (jin == G - 1)
+            __hip_atomic_store(gstat + (size_t)grp * RADIX + t, RS_FLAG_GLOBAL | (uint64_t)(pre + total[0]), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t gpre = 0;
+        for (uint32_t g0 = 0; g0 < grp && !gave_up; g0 += G) {
+            const uint64_t* row = gstat + (size_t)g0 * RADIX + t;
+            const uint32_t cnt = min(G, grp - g0);
+            uint64_t w[G];
+            bool all;
+            do {
 #pragma unroll
-        for (int j = 0; j < DPT; ++j) gbase[t * DPT + j] = gdigit_base[j] + (uint32_t)prefix[j] - dbase[j];
+                for (uint32_t q = 0; q < G; ++q)
+                    w[q] = q < cnt ? __hip_atomic_load(row + (size_t)q * RADIX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : RS_FLAG_GLOBAL;
+                all = true;
+#pragma unroll
+                for (uint32_t q = 0; q < G; ++q) all &= (w[q] >> 62) != 0ull;
+                if (!all) {
+                    if (++spins > g_rs_spin_limit) { atomicExch(a.error + a.pass, 1u); gave_up = true; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            } while (!all && !gave_up);
+#pragma unroll
+            for (uint32_t q = 0; q < G; ++q) gpre += (uint32_t)(w[q] & RS_COUNT_MASK);
+        }
+        gbase[t] = gdigit_base[0] + gpre + pre - dbase[0];
         __syncthreads();
     }
 
@@ -836,11 +832,11 @@ static void rs_launch_pass_items(const RsPassArgs& a, int items, bool scanned, u
     if (scanned) {
         if (items == RS_ITEMS_WIDE) rs_launch_pass<RS_ITEMS_WIDE, DB, true, PAYLOAD>(a, tiles, ballot, s);
         else rs_launch_pass<RS_ITEMS, DB, true, PAYLOAD>(a, tiles, ballot, s);
-    } else if (PAYLOAD) {
-        // (payloads only travel on the counted-tiles path)
-    } else if (items == RS_ITEMS_SMALL) rs_launch_pass<RS_ITEMS_SMALL, DB, false, false>(a, tiles, ballot, s);
-    else if (items == RS_ITEMS_MID) rs_launch_pass<RS_ITEMS_MID, DB, false, false>(a, tiles, ballot, s);
-    else rs_launch_pass<RS_ITEMS, DB, false, false>(a, tiles, ballot, s);
+    } else if constexpr (!PAYLOAD && DB == 8) {        // (payloads and 9-bit digits only exist on the counted-tiles path)
+        if (items == RS_ITEMS_SMALL) rs_launch_pass<RS_ITEMS_SMALL, 8, false, false>(a, tiles, ballot, s);
+        else if (items == RS_ITEMS_MID) rs_launch_pass<RS_ITEMS_MID, 8, false, false>(a, tiles, ballot, s);
+        else rs_launch_pass<RS_ITEMS, 8, false, false>(a, tiles, ballot, s);
+    }
 }
 
 struct RsBuffers {
@@ -884,7 +880,8 @@ static int rs_run(const RsPlan& pl, const RsBuffers& b, uint64_t n, void* temp, 
         a.kin = kin; a.vin = vin; a.pin = pin; a.kout = kout; a.vout = vout; a.pout = pout;
         a.n = (uint32_t)n; a.n_dev = n_dev; a.shift = pl.shift[p]; a.sub = pl.sub;
         a.hist = ghist + p * hstride;
-        a.status = t.status + (size_t)p * tiles * pl.radix;
+        a.status = t.status + (size_t)p * rs_status_rows(tiles) * pl.radix;
+        a.tiles = tiles;
         // <= one workgroup per CU: the whole grid is co-resident whatever the dispatch order, so block ids are safe
         a.ticket = tiles <= 256u ? nullptr : t.tickets + p;
         a.error = t.error;

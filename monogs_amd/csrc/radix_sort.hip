@@ -8,12 +8,12 @@
 // lays the tile out digit by digit in LDS and writes each digit's run to its final place (coalesced runs instead of a
 // 256-way scatter).  Two ways of knowing where a tile's runs go, bit-identical results, chosen by size (rs_scanned()):
 //
-// "One sweep" (<= 640 k pairs: every sort of a SLAM-sized map; fewest launches):
+// "One sweep" (<= 512 k pairs: the sorts of a SLAM-sized map at VGA; fewest launches):
 //   * ONE histogram kernel reads the keys once and counts every digit of every pass (each pass kernel
 //     scans its 256 counts into exclusive global bases itself);
 //   * per pass ONE kernel: the tile publishes its 256 digit counts and obtains the sum of the counts of all EARLIER
 //     tiles by decoupled look-back.
-// "Counted tiles" (> 640 k pairs; rs_scanned): per pass rs_tile_hist_kernel writes the digit counts of every tile,
+// "Counted tiles" (> 512 k pairs; rs_scanned): per pass rs_tile_hist_kernel writes the digit counts of every tile,
 //   counts[tile][digit], and adds them into the rows of the tile's ancestors in a tree of fan-out 8 over the tiles; the
 //   scatter kernel sums the siblings before each of its ancestors (<= 7 rows per level, <= 16 at the top, all requested
 //   together before the keys: one round trip hidden behind the key loads) -- no waiting between workgroups, and no scan
@@ -76,9 +76,14 @@ constexpr int RS_ITEMS_SMALL = 4;                  // small sorts are latency-bo
 // Measured on MI355X with the ballot ranking (depth sort of P keys): 40 k: 72 us (16) -> 50 us (4); 400 k: 122 us (32) / 83 us (8);
 // 400 k: 108 us (4); 2 M: 158 us (16) / 208 us (8) / 152 us (32).  A few hundred tiles is the sweet spot between the
 // per-tile latency and the length of the look-back chain.
-// Above this many pairs the counted-tiles path takes over.  Round 2: 1 M keys (depth sort): one sweep 0.134 ms, counted
-// 0.101 ms; 500 k: 0.087 vs 0.092 ms; 300 k: 0.075 vs 0.088 ms -- the crossover sits between 512 k and 1 M.
-constexpr uint64_t RS_ONE_SWEEP_MAX = 640ull * 1024;
+// Above this many pairs the counted-tiles path takes over.  Round 3, after both paths changed (LDS-atomic ranking, the
+// tree of counts instead of a scan launch, the all-gather instead of the look-back walk), whole sort in us, one sweep /
+// counted tiles: tile sort 100 k: 29.1 / 32.6, 200 k: 33.5 / 33.1, 300 k: 35.7 / 33.8, 415 k: 38.3 / 34.5, 640 k: 50.0 / 37.5;
+// depth sort 200 k: 59.6 / 62.1, 300 k: 63.2 / 63.8, 415 k: 67.0 / 65.8, 640 k: 92.4 / 71.2 (round 2 had it between 512 k and 1 M).
+// Inside a hipGraph replay every kernel node costs ~4.8 us whatever it does, and the counted path has twice the launches:
+// the captured TUM-like run (39 k Gaussians, 415 k instances) tracks at 4171 it/s with the one-sweep tile sort against
+// 4088 with counted tiles, the Replica-like one (103 k, ~1 M instances) at 1653 against 1724.
+constexpr uint64_t RS_ONE_SWEEP_MAX = 512ull * 1024;
 static inline int rs_items(uint64_t n) {
     return n <= 192ull * 1024 ? RS_ITEMS_SMALL : (n <= RS_ONE_SWEEP_MAX ? RS_ITEMS_MID : RS_ITEMS);
 }
@@ -106,9 +111,10 @@ __device__ __forceinline__ uint32_t rs_xf(uint32_t k, uint32_t sub) { return k =
 // large sorts take the counted-tiles path; a test knob forces either one (no environment lookups on the launch path)
 int g_opt_radix_scanned = -1;       // mgs_debug_set_option("radix_scanned", -1 | 0 | 1): -1 = by size
 int g_opt_radix_ballot_rank = 0;    // mgs_debug_set_option("radix_ballot_rank", 1): rank with ballots instead of LDS atomics
+constexpr uint64_t RS_SCANNED_MIN = 64ull * 1024;       // the knob can force counted tiles down to here
 static inline bool rs_scanned(uint64_t n) {
-    if (g_opt_radix_scanned >= 0) return g_opt_radix_scanned == 1 && rs_items(n) == RS_ITEMS;
-    return rs_items(n) == RS_ITEMS;          // > 640 k pairs: hundreds of tiles
+    if (g_opt_radix_scanned >= 0) return g_opt_radix_scanned == 1 && n > RS_SCANNED_MIN;
+    return n > RS_ONE_SWEEP_MAX;
 }
 // Pairs per thread.  On the counted-tiles path a tile lives ~10-20 us and the kernel ends when the last one does: if the
 // tiles do not all fit on the chip at once, the stragglers start when the first ones retire and the pass takes two tile
@@ -116,8 +122,7 @@ static inline bool rs_scanned(uint64_t n) {
 // tiles: 84-92 VGPRs + 24 KB of LDS = 4-5 workgroups per CU; 3072-pair tiles: 72 VGPRs + 20 KB = 7 per CU (1792), and 1716
 // tiles at C5 (82.7 us against 85.9; 2048-pair tiles lose it again to the doubled count tables, 104.6 us).
 static inline int rs_tile_items(uint64_t n, bool scanned) {
-    const int it = rs_items(n);
-    if (it != RS_ITEMS || !scanned) return it;
+    if (!scanned) return rs_items(n);
     return n > 1024ull * RS_THREADS * RS_ITEMS ? RS_ITEMS_WIDE : RS_ITEMS;
 }
 static inline uint32_t rs_tiles(uint64_t n, bool scanned) {
@@ -227,7 +232,7 @@ static size_t rs_temp_bytes(uint64_t n, const RsPlan& pl) {
     if (n == 0) return 256;
     // either path may be forced on a buffer sized earlier (test knob): size for the larger one
     const size_t a = rs_carve(nullptr, n, pl, false).bytes;
-    const size_t b = rs_items(n) == RS_ITEMS ? rs_carve(nullptr, n, pl, true).bytes : 0;
+    const size_t b = n > RS_SCANNED_MIN ? rs_carve(nullptr, n, pl, true).bytes : 0;
     return (a > b ? a : b) + 512;
 }
 size_t radix_temp_bytes(uint64_t n, int bits) { return rs_temp_bytes(n, rs_plan_plain(bits)); }

@@ -5,7 +5,7 @@ it on 64-bit (tile | depth) keys): a STABLE sort.  The library ranks a pair insi
 per item; that is stable only if the LDS unit applies the lanes of one DS instruction to one address in ascending lane
 order, which is what these cases pin: keys with one to five distinct digits (every wave-instruction full of equal
 digits) must come out exactly as torch's stable sort and as the ballot ranking (the first implementation, kept as a
-test knob) put them, on every path (1024 / 2048-pair tiles with look-back, 3072 / 4096-pair counted tiles)."""
+test knob) put them, on every path (1024 / 2048-pair tiles with the all-gather of counts, 3072 / 4096-pair counted tiles)."""
 import pytest
 import torch
 
@@ -44,7 +44,7 @@ def _keys(kind, n, bits, gen):
     raise ValueError(kind)
 
 
-# sizes that take every kernel configuration: 1024-pair tiles (<= 192 k), 2048-pair (<= 640 k), counted tiles of 4096
+# sizes that take every kernel configuration: 1024-pair tiles (<= 192 k), 2048-pair (<= 512 k), counted tiles of 4096
 # pairs (one tile per histogram workgroup) and of 3072 pairs (four tiles per histogram workgroup), a ragged last tile each
 @pytest.mark.parametrize("n", [1, 63, 1025, 150_001, 500_003, 1_200_007, 4_300_001])
 @pytest.mark.parametrize("kind,bits", [("uniform", 32), ("five", 16), ("one", 32), ("sorted", 13), ("depth", 32)])

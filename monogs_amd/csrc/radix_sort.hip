@@ -431,6 +431,58 @@ __device__ __forceinline__ void rs_exchange(uint32_t* __restrict__ sbuf, const u
     for (int i = 0; i < ITEMS; ++i) x[i] = sbuf[min((uint32_t)i * RS_THREADS + (uint32_t)t, (uint32_t)(RS_THREADS * ITEMS - 1))];
 }
 
+// exclusive global base of a thread's digits = block-wide scan of this pass's digit totals (cheaper inside the scatter
+// kernel than a launch of its own)
+template <int DPT>
+__device__ __forceinline__ void rs_digit_bases(const uint32_t (&hcount)[DPT], uint32_t (&gdigit_base)[DPT], uint32_t* wsum, int lane, int wv) {
+    uint32_t hsum = 0;
+#pragma unroll
+    for (int j = 0; j < DPT; ++j) hsum += hcount[j];
+    const uint32_t hincl = wave_incl_scan_dpp(hsum);
+    __syncthreads();                     // wsum is reused
+    if (lane == 63) wsum[wv] = hincl;
+    __syncthreads();
+    uint32_t hadd = 0;
+    for (int w = 0; w < wv; ++w) hadd += wsum[w];
+    uint32_t run = hadd + hincl - hsum;
+#pragma unroll
+    for (int j = 0; j < DPT; ++j) { gdigit_base[j] = run; run += hcount[j]; }
+}
+
+// one-sweep all-gather: adds the counts of the status rows [0, cnt) (stride `stride` words, this thread's digit) -- all
+// of them into `all`, those below `before` into `pre`; row `skip` is not read (the tile's own).  RS_GROUP rows per batch
+// of loads; spins (bounded) until every word of the batch is published.  Returns false if it gave up.
+__device__ __forceinline__ bool rs_gather(const uint64_t* row, size_t stride, uint32_t cnt, uint32_t before, uint32_t skip,
+                                          uint32_t& pre, uint32_t& all, uint32_t& spins, uint32_t* err) {
+    constexpr uint32_t G = RS_GROUP;
+    for (uint32_t r0 = 0; r0 < cnt; r0 += G) {
+        uint64_t w[G];
+        bool ready;
+        do {
+#pragma unroll
+            for (uint32_t q = 0; q < G; ++q) {
+                const uint32_t r = r0 + q;
+                w[q] = (r < cnt && r != skip) ? __hip_atomic_load(row + (size_t)r * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                              : RS_FLAG_GLOBAL;          // nothing there: published, count 0
+            }
+            ready = true;
+#pragma unroll
+            for (uint32_t q = 0; q < G; ++q) ready &= (w[q] >> 62) != 0ull;
+            if (!ready) {
+                if (++spins > g_rs_spin_limit) { atomicExch(err, 1u); return false; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        } while (!ready);
+#pragma unroll
+        for (uint32_t q = 0; q < G; ++q) {
+            const uint32_t c = (uint32_t)(w[q] & RS_COUNT_MASK);
+            all += c;
+            pre += (r0 + q) < before ? c : 0u;
+        }
+    }
+    return true;
+}
+
 // DB:              digit bits, 8 or 9: 256 or 512 digits, one or two (adjacent) per thread.
 // SCANNED = false: one sweep -- the tile publishes its digit counts and finds the sum over earlier tiles by decoupled
 //                  look-back (fewest launches: right for the small sorts of SLAM-sized maps).
@@ -516,7 +568,7 @@ __global__ void __launch_bounds__(RS_THREADS, (SCANNED && ITEMS == RS_ITEMS_WIDE
         }
     } else {
 #pragma unroll
-        for (int j = 0; j < DPT; ++j) hcount[j] = a.hist[t * DPT + j];
+        for (int j = 0; j < DPT; ++j) hcount[j] = a.hist ? a.hist[t * DPT + j] : 0u;
     }
 
     // ---- load (wave-striped: item i of lane l of wave w is element w*(ITEMS*64) + i*64 + l of the tile) and rank
@@ -606,7 +658,7 @@ __global__ void __launch_bounds__(RS_THREADS, (SCANNED && ITEMS == RS_ITEMS_WIDE
     RS_STAMP(2);
 
     // ---- thread t owns digits t * DPT + j: per-wave exclusive prefixes, tile totals, position of the digit inside the tile
-    uint32_t total[DPT], tsum = 0, hsum = 0;
+    uint32_t total[DPT], tsum = 0;
 #pragma unroll
     for (int j = 0; j < DPT; ++j) {
         uint32_t run = 0;
@@ -618,7 +670,6 @@ __global__ void __launch_bounds__(RS_THREADS, (SCANNED && ITEMS == RS_ITEMS_WIDE
         }
         total[j] = run;
         tsum += run;
-        hsum += hcount[j];
     }
     const uint32_t incl = wave_incl_scan_dpp(tsum);
     if (lane == 63) wsum[wv] = incl;
@@ -631,83 +682,44 @@ __global__ void __launch_bounds__(RS_THREADS, (SCANNED && ITEMS == RS_ITEMS_WIDE
 #pragma unroll
         for (int j = 0; j < DPT; ++j) { dbase[j] = run; digit_base[t * DPT + j] = run; run += total[j]; }
     }
-    // exclusive global base of the digits = scan of this pass's digit totals: cheaper here than a separate launch
-    const uint32_t hincl = wave_incl_scan_dpp(hsum);
-    __syncthreads();                     // wsum is reused
-    if (lane == 63) wsum[wv] = hincl;
-    __syncthreads();
-    uint32_t hadd = 0;
-    for (int w = 0; w < wv; ++w) hadd += wsum[w];
     uint32_t gdigit_base[DPT];
-    {
-        uint32_t run = hadd + hincl - hsum;
-#pragma unroll
-        for (int j = 0; j < DPT; ++j) { gdigit_base[j] = run; run += hcount[j]; }
-    }
     if constexpr (SCANNED) {
+        rs_digit_bases<DPT>(hcount, gdigit_base, wsum, lane, wv);
 #pragma unroll
         for (int j = 0; j < DPT; ++j) gbase[t * DPT + j] = gdigit_base[j] + before[j] - dbase[j];
         __syncthreads();
     } else {
         // ---- publish, gather, publish: a two-level all-gather of the tiles' digit counts (one digit per thread).
-        // Every tile publishes its counts; it reads the counts of the <= 15 tiles before it in its group of 16 in ONE
-        // batch of loads; the last tile of a group publishes the group's sum; every tile reads the sums of the groups
-        // before its own, 16 per batch.  Two dependent round trips whatever the number of tiles.  (The first version
-        // walked back 16 predecessors at a time until it met a tile that had already published an INCLUSIVE count: with
-        // every tile of a small sort starting together nobody has one early, and tile T paid ~T/16 dependent round
-        // trips -- 4.4 us of a tile's 9.8 us at 40 tiles, 7.7 of 12 us at 203, tools/ubench/sort_bench.)
-        // A tile only waits for tiles with a smaller ticket, which have started; the spins are bounded.
+        // Every tile publishes its counts; it reads the counts of the tiles of its group of 16 in ONE batch of loads; the
+        // last tile of a group publishes the group's sum; every tile reads the group sums, 16 per batch.  Two dependent
+        // round trips whatever the number of tiles.  (The first version walked back 16 predecessors at a time until it
+        // met a tile that had already published an INCLUSIVE count: with every tile of a small sort starting together
+        // nobody has one early, and tile T paid ~T/16 dependent round trips -- 4.4 us of a tile's 9.8 us at 40 tiles,
+        // 7.7 of 12 us at 203, tools/ubench/sort_bench.)
+        // Up to 256 tiles (one per CU: co-resident by construction -- every sort this path is chosen for) a tile reads
+        // the counts of ALL tiles, later ones included: the digit totals then come out of the gather and no histogram
+        // kernel runs before the passes (a.hist == NULL).  Beyond (the path forced by the test knob) it only waits for
+        // tiles with a smaller ticket, which have started, and takes the totals from the histogram.  Spins are bounded.
         static_assert(DPT == 1, "the one-sweep path ranks 256 digits");
         constexpr uint32_t G = RS_GROUP;
+        const bool everything = a.hist == nullptr;
+        const uint32_t live_tiles = (n_live + (uint32_t)TILE_PAIRS - 1) / (uint32_t)TILE_PAIRS;
         const uint32_t grp = tile / G, jin = tile % G;                  // wave-uniform
+        const uint32_t members = min(G, live_tiles - grp * G), groups = (live_tiles + G - 1) / G;
         uint64_t* gstat = a.status + (size_t)a.tiles * RADIX;           // the group words follow the tiles' words
+        if (!everything) rs_digit_bases<DPT>(hcount, gdigit_base, wsum, lane, wv);
         __hip_atomic_store(a.status + (size_t)tile * RADIX + t, RS_FLAG_LOCAL | (uint64_t)total[0], __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
-        uint32_t spins = 0;
-        bool gave_up = false;
-        uint32_t pre = 0;
-        if (jin > 0) {
-            const uint64_t* row = a.status + (size_t)grp * G * RADIX + t;
-            uint64_t w[G - 1];
-            bool all;
-            do {
-#pragma unroll
-                for (uint32_t q = 0; q < G - 1; ++q)
-                    w[q] = q < jin ? __hip_atomic_load(row + (size_t)q * RADIX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : RS_FLAG_LOCAL;
-                all = true;
-#pragma unroll
-                for (uint32_t q = 0; q < G - 1; ++q) all &= (w[q] >> 62) != 0ull;
-                if (!all) {
-                    if (++spins > g_rs_spin_limit) { atomicExch(a.error + a.pass, 1u); gave_up = true; }
-                    __builtin_amdgcn_s_sleep(1);
-                }
-            } while (!all && !gave_up);
-#pragma unroll
-            for (uint32_t q = 0; q < G - 1; ++q) pre += (uint32_t)(w[q] & RS_COUNT_MASK);
-        }
-        if (jin == G - 1)
+        uint32_t spins = 0, pre = 0, in_group = 0, gpre = 0, gall = 0;
+        bool ok = rs_gather(a.status + (size_t)grp * G * RADIX + t, RADIX, everything ? members : jin, jin, jin, pre, in_group,
+                            spins, a.error + a.pass);
+        if (jin == members - 1)      // (then `pre` covers the whole group but this tile)
             __hip_atomic_store(gstat + (size_t)grp * RADIX + t, RS_FLAG_GLOBAL | (uint64_t)(pre + total[0]), __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
-        uint32_t gpre = 0;
-        for (uint32_t g0 = 0; g0 < grp && !gave_up; g0 += G) {
-            const uint64_t* row = gstat + (size_t)g0 * RADIX + t;
-            const uint32_t cnt = min(G, grp - g0);
-            uint64_t w[G];
-            bool all;
-            do {
-#pragma unroll
-                for (uint32_t q = 0; q < G; ++q)
-                    w[q] = q < cnt ? __hip_atomic_load(row + (size_t)q * RADIX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : RS_FLAG_GLOBAL;
-                all = true;
-#pragma unroll
-                for (uint32_t q = 0; q < G; ++q) all &= (w[q] >> 62) != 0ull;
-                if (!all) {
-                    if (++spins > g_rs_spin_limit) { atomicExch(a.error + a.pass, 1u); gave_up = true; }
-                    __builtin_amdgcn_s_sleep(1);
-                }
-            } while (!all && !gave_up);
-#pragma unroll
-            for (uint32_t q = 0; q < G; ++q) gpre += (uint32_t)(w[q] & RS_COUNT_MASK);
+        if (ok) ok = rs_gather(gstat + t, RADIX, everything ? groups : grp, grp, 0xFFFFFFFFu, gpre, gall, spins, a.error + a.pass);
+        if (everything) {
+            hcount[0] = gall;
+            rs_digit_bases<DPT>(hcount, gdigit_base, wsum, lane, wv);
         }
         gbase[t] = gdigit_base[0] + gpre + pre - dbase[0];
         __syncthreads();
@@ -819,7 +831,7 @@ void radix_depth_zero_region(void* temp, uint64_t n, uint32_t** ptr, size_t* wor
 }
 
 // does a sort of n pairs read a global digit histogram (one-sweep path) -- i.e. is it worth counting one while the keys are produced?
-bool radix_wants_hist(uint64_t n) { return n > 0 && !rs_scanned(n); }
+bool radix_wants_hist(uint64_t n) { return n > 0 && !rs_scanned(n) && rs_tiles(n, false) > 256u; }
 // does the depth sort of n Gaussians carry the rectangle as a payload (else it gathers it in its final pass)?
 bool radix_depth_payload(uint64_t n) { return n > 0 && rs_scanned(n); }
 
@@ -869,7 +881,9 @@ static int rs_run(const RsPlan& pl, const RsBuffers& b, uint64_t n, void* temp, 
     ta.levels = tree.levels;
     for (int l = 0; l < RS_MAX_LEVELS; ++l) ta.off[l] = l < tree.levels ? tree.off[l] : 0u;
     ta.top_rows = tree.rows[tree.levels - 1];
-    if (!scanned && !ext_hist) {
+    // one sweep, <= 256 tiles (every sort that takes this path by itself): the digit totals come out of the all-gather
+    const bool gather_all = !scanned && tiles <= 256u;
+    if (!scanned && !ext_hist && !gather_all) {
         RsHistArgs h;
         h.npasses = pl.npasses; h.radix = pl.radix; h.sub = pl.sub; h.wide = pl.depth ? t.wide : nullptr;
         for (int p = 0; p < RS_MAX_PASSES; ++p) { h.shift[p] = pl.shift[p]; h.mask[p] = (1 << pl.db[p]) - 1; }
@@ -884,7 +898,7 @@ static int rs_run(const RsPlan& pl, const RsBuffers& b, uint64_t n, void* temp, 
         RsPassArgs a;
         a.kin = kin; a.vin = vin; a.pin = pin; a.kout = kout; a.vout = vout; a.pout = pout;
         a.n = (uint32_t)n; a.n_dev = n_dev; a.shift = pl.shift[p]; a.sub = pl.sub;
-        a.hist = ghist + p * hstride;
+        a.hist = gather_all ? nullptr : ghist + p * hstride;
         a.status = t.status + (size_t)p * rs_status_rows(tiles) * pl.radix;
         a.tiles = tiles;
         // <= one workgroup per CU: the whole grid is co-resident whatever the dispatch order, so block ids are safe

@@ -328,9 +328,29 @@ __global__ void __launch_bounds__(256) preprocess_forward_kernel(PreArgs a) {
         a.rect[idx] = vis ? o.rect : make_uint2(0u, 0u);
     }
     a.depth_key[idx] = vis ? o.key : 0xFFFFFFFFu;
-    if (vis) {
-        float4* rec = reinterpret_cast<float4*>(a.rec + (size_t)idx * REC_FLOATS);
-        rec[0] = o.r0; rec[1] = o.r1; rec[2] = o.r2; rec[3] = o.r3;
+    {
+        // The 64-byte record.  A lane writing its own record is four store instructions of 16 bytes every 64 bytes: each
+        // touches all 64 lines of the wave's 4 KB a quarter each.  A full wave hands its records over through LDS instead
+        // (rows of 80 bytes: conflict-free 16-byte writes) and lane l stores 16 bytes of the records (l >> 2) + 16 k,
+        // k = 0..3: each store instruction covers one contiguous KB minus the culled Gaussians' holes -- the shape the
+        // gradient-line clear below already has.
+        __shared__ float4 s_rec[4][WAVE * 5];
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, wave_first = idx - lane;
+        if (wave_first + WAVE <= a.P) {                       // wave-uniform: every lane is here
+            const unsigned long long vm = __builtin_amdgcn_ballot_w64(vis);
+            float4* mine = s_rec[wv] + lane * 5;
+            mine[0] = o.r0; mine[1] = o.r1; mine[2] = o.r2; mine[3] = o.r3;
+            float4* base = reinterpret_cast<float4*>(a.rec + (size_t)wave_first * REC_FLOATS);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int src = (lane >> 2) + 16 * k;
+                const float4 v = s_rec[wv][src * 5 + (lane & 3)];
+                if ((vm >> src) & 1ull) base[k * WAVE + lane] = v;
+            }
+        } else if (vis) {
+            float4* rec = reinterpret_cast<float4*>(a.rec + (size_t)idx * REC_FLOATS);
+            rec[0] = o.r0; rec[1] = o.r1; rec[2] = o.r2; rec[3] = o.r3;
+        }
     }
     if (a.grad_acc) {
         // The blend backward adds into the 64-byte gradient line of a visible Gaussian and the per-Gaussian backward reads
@@ -425,8 +445,17 @@ __global__ void __launch_bounds__(256) geom_backward_kernel(BwdArgs a) {
     const int rad = a.g.radii[ci];
     const float x = a.g.means3D[3 * ci], y = a.g.means3D[3 * ci + 1], z = a.g.means3D[3 * ci + 2];
     const float opq = a.g.opacities[ci];
-    const float4* gl = reinterpret_cast<const float4*>(a.g.grad_acc + ci * GRAD_FLOATS);
-    const float4 ga0 = gl[0], ga1 = gl[1], ga2 = gl[2];
+    // the 64-byte line of blend sums: a full wave fetches its 64 lines with four coalesced 1-KB loads (lane l takes 16 bytes
+    // of the lines (l >> 2) + 16 k) and deals them out through LDS (rows of 80 bytes), instead of three loads per lane
+    // that each touch all 64 lines a quarter each
+    __shared__ float4 s_ga[4][WAVE * 5];
+    const int lane_ = threadIdx.x & 63, wv_ = threadIdx.x >> 6, wave_first = idx - lane_;
+    const bool full_wave = wave_first + WAVE <= a.P;          // wave-uniform
+    // (full wave: t_k = 16 bytes of line (lane >> 2) + 16 k; else t_0..t_2 = this lane's own line)
+    const float4* gsrc = full_wave ? reinterpret_cast<const float4*>(a.g.grad_acc + (size_t)wave_first * GRAD_FLOATS) + lane_
+                                   : reinterpret_cast<const float4*>(a.g.grad_acc + ci * GRAD_FLOATS);
+    const int gstep = full_wave ? WAVE : 1;
+    const float4 t0 = gsrc[0], t1 = gsrc[gstep], t2 = gsrc[2 * gstep], t3 = gsrc[3 * gstep];
     float cov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, Mm[9];
     float s[3] = {0.f, 0.f, 0.f}, q[4] = {1.f, 0.f, 0.f, 0.f};
     if (COV) {
@@ -440,8 +469,13 @@ __global__ void __launch_bounds__(256) geom_backward_kernel(BwdArgs a) {
         load4(a.g.rotations + 4 * ci, a.rot_aligned16 != 0, q);
         asm volatile("" ::"v"(s[0]), "v"(s[1]), "v"(s[2]), "v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(q[3]));
     }
-    asm volatile("" ::"v"(rad), "v"(x), "v"(y), "v"(z), "v"(opq), "v"(ga0.x), "v"(ga0.y), "v"(ga0.z), "v"(ga0.w), "v"(ga1.x),
-                 "v"(ga1.y), "v"(ga1.z), "v"(ga1.w), "v"(ga2.x), "v"(ga2.y));
+    asm volatile("" ::"v"(rad), "v"(x), "v"(y), "v"(z), "v"(opq));
+    float4 ga0 = t0, ga1 = t1, ga2 = t2;
+    if (full_wave) {
+        float4* row = s_ga[wv_] + (lane_ >> 2) * 5 + (lane_ & 3);
+        row[0] = t0; row[16 * 5] = t1; row[32 * 5] = t2; row[48 * 5] = t3;
+        ga0 = s_ga[wv_][lane_ * 5 + 0]; ga1 = s_ga[wv_][lane_ * 5 + 1]; ga2 = s_ga[wv_][lane_ * 5 + 2];
+    }
     pin_cam(c, true);
     const float ga[GRAD_FLOATS] = {ga0.x, ga0.y, ga0.z, ga0.w, ga1.x, ga1.y, ga1.z, ga1.w, ga2.x, ga2.y, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const bool live = in && rad > 0;

@@ -12,7 +12,7 @@
 //   * ONE histogram kernel reads the keys once and counts every digit of every pass (each pass kernel
 //     scans its 256 counts into exclusive global bases itself);
 //   * per pass ONE kernel: the tile publishes its 256 digit counts and obtains the sum of the counts of all EARLIER
-//     tiles by decoupled look-back.
+//     tiles by a two-level gather (its group of 16, then the group sums).
 // "Counted tiles" (> 512 k pairs; rs_scanned): per pass rs_tile_hist_kernel writes the digit counts of every tile,
 //   counts[tile][digit], and adds them into the rows of the tile's ancestors in a tree of fan-out 8 over the tiles; the
 //   scatter kernel sums the siblings before each of its ancestors (<= 7 rows per level, <= 16 at the top, all requested
@@ -449,10 +449,10 @@ __device__ __forceinline__ void rs_digit_bases(const uint32_t (&hcount)[DPT], ui
     for (int j = 0; j < DPT; ++j) { gdigit_base[j] = run; run += hcount[j]; }
 }
 
-// one-sweep all-gather: adds the counts of the status rows [0, cnt) (stride `stride` words, this thread's digit) -- all
-// of them into `all`, those below `before` into `pre`; row `skip` is not read (the tile's own).  RS_GROUP rows per batch
-// of loads; spins (bounded) until every word of the batch is published.  Returns false if it gave up.
-__device__ __forceinline__ bool rs_gather(const uint64_t* row, size_t stride, uint32_t cnt, uint32_t before, uint32_t skip,
+// one-sweep gather: adds the counts of the status rows [0, cnt) (stride `stride` words, this thread's digit) -- all of them
+// into `all`, those below `before` into `pre`.  RS_GROUP rows per batch of loads; spins (bounded) until every word of the
+// batch is published.  Returns false if it gave up.
+__device__ __forceinline__ bool rs_gather(const uint64_t* row, size_t stride, uint32_t cnt, uint32_t before,
                                           uint32_t& pre, uint32_t& all, uint32_t& spins, uint32_t* err) {
     constexpr uint32_t G = RS_GROUP;
     for (uint32_t r0 = 0; r0 < cnt; r0 += G) {
@@ -462,7 +462,7 @@ __device__ __forceinline__ bool rs_gather(const uint64_t* row, size_t stride, ui
 #pragma unroll
             for (uint32_t q = 0; q < G; ++q) {
                 const uint32_t r = r0 + q;
-                w[q] = (r < cnt && r != skip) ? __hip_atomic_load(row + (size_t)r * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                w[q] = r < cnt ? __hip_atomic_load(row + (size_t)r * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
                                               : RS_FLAG_GLOBAL;          // nothing there: published, count 0
             }
             ready = true;
@@ -568,7 +568,7 @@ __global__ void __launch_bounds__(RS_THREADS, (SCANNED && ITEMS == RS_ITEMS_WIDE
         }
     } else {
 #pragma unroll
-        for (int j = 0; j < DPT; ++j) hcount[j] = a.hist ? a.hist[t * DPT + j] : 0u;
+        for (int j = 0; j < DPT; ++j) hcount[j] = a.hist[t * DPT + j];
     }
 
     // ---- load (wave-striped: item i of lane l of wave w is element w*(ITEMS*64) + i*64 + l of the tile) and rank
@@ -696,31 +696,28 @@ __global__ void __launch_bounds__(RS_THREADS, (SCANNED && ITEMS == RS_ITEMS_WIDE
         // met a tile that had already published an INCLUSIVE count: with every tile of a small sort starting together
         // nobody has one early, and tile T paid ~T/16 dependent round trips -- 4.4 us of a tile's 9.8 us at 40 tiles,
         // 7.7 of 12 us at 203, tools/ubench/sort_bench.)
-        // Up to 256 tiles (one per CU: co-resident by construction -- every sort this path is chosen for) a tile reads
-        // the counts of ALL tiles, later ones included: the digit totals then come out of the gather and no histogram
-        // kernel runs before the passes (a.hist == NULL).  Beyond (the path forced by the test knob) it only waits for
-        // tiles with a smaller ticket, which have started, and takes the totals from the histogram.  Spins are bounded.
+        // A tile only waits for tiles with a smaller id, which were dispatched before it (or, past 256 tiles, took their
+        // ticket before it): they are resident or done whatever else runs on the chip.  (Round 3 also tried reading ALL
+        // tiles' counts, later ones included, so that the digit totals come out of the gather and no histogram kernel
+        // runs: 4.8 us less per depth sort inside a replay -- but a tile that waits for a LATER tile needs the whole grid
+        // resident, and the eight keyframes of a mapping window sort at the same time on eight streams: 8 x 203 tiles
+        // of the VGA tile sort against 1536 slots can leave every resident tile waiting for one that cannot start.
+        // Removed; the totals come from the histogram the key producer or rs_hist_kernel counted.)  Spins are bounded.
         static_assert(DPT == 1, "the one-sweep path ranks 256 digits");
         constexpr uint32_t G = RS_GROUP;
-        const bool everything = a.hist == nullptr;
         const uint32_t live_tiles = (n_live + (uint32_t)TILE_PAIRS - 1) / (uint32_t)TILE_PAIRS;
         const uint32_t grp = tile / G, jin = tile % G;                  // wave-uniform
-        const uint32_t members = min(G, live_tiles - grp * G), groups = (live_tiles + G - 1) / G;
+        const uint32_t members = min(G, live_tiles - grp * G);
         uint64_t* gstat = a.status + (size_t)a.tiles * RADIX;           // the group words follow the tiles' words
-        if (!everything) rs_digit_bases<DPT>(hcount, gdigit_base, wsum, lane, wv);
+        rs_digit_bases<DPT>(hcount, gdigit_base, wsum, lane, wv);
         __hip_atomic_store(a.status + (size_t)tile * RADIX + t, RS_FLAG_LOCAL | (uint64_t)total[0], __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
-        uint32_t spins = 0, pre = 0, in_group = 0, gpre = 0, gall = 0;
-        bool ok = rs_gather(a.status + (size_t)grp * G * RADIX + t, RADIX, everything ? members : jin, jin, jin, pre, in_group,
-                            spins, a.error + a.pass);
-        if (jin == members - 1)      // (then `pre` covers the whole group but this tile)
+        uint32_t spins = 0, pre = 0, gpre = 0, unused = 0;
+        bool ok = rs_gather(a.status + (size_t)grp * G * RADIX + t, RADIX, jin, jin, pre, unused, spins, a.error + a.pass);
+        if (jin == members - 1)      // the group's last live tile: `pre` covers the whole group but this tile
             __hip_atomic_store(gstat + (size_t)grp * RADIX + t, RS_FLAG_GLOBAL | (uint64_t)(pre + total[0]), __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
-        if (ok) ok = rs_gather(gstat + t, RADIX, everything ? groups : grp, grp, 0xFFFFFFFFu, gpre, gall, spins, a.error + a.pass);
-        if (everything) {
-            hcount[0] = gall;
-            rs_digit_bases<DPT>(hcount, gdigit_base, wsum, lane, wv);
-        }
+        if (ok) ok = rs_gather(gstat + t, RADIX, grp, grp, gpre, unused, spins, a.error + a.pass);
         gbase[t] = gdigit_base[0] + gpre + pre - dbase[0];
         __syncthreads();
     }
@@ -831,7 +828,7 @@ void radix_depth_zero_region(void* temp, uint64_t n, uint32_t** ptr, size_t* wor
 }
 
 // does a sort of n pairs read a global digit histogram (one-sweep path) -- i.e. is it worth counting one while the keys are produced?
-bool radix_wants_hist(uint64_t n) { return n > 0 && !rs_scanned(n) && rs_tiles(n, false) > 256u; }
+bool radix_wants_hist(uint64_t n) { return n > 0 && !rs_scanned(n); }
 // does the depth sort of n Gaussians carry the rectangle as a payload (else it gathers it in its final pass)?
 bool radix_depth_payload(uint64_t n) { return n > 0 && rs_scanned(n); }
 
@@ -881,9 +878,7 @@ static int rs_run(const RsPlan& pl, const RsBuffers& b, uint64_t n, void* temp, 
     ta.levels = tree.levels;
     for (int l = 0; l < RS_MAX_LEVELS; ++l) ta.off[l] = l < tree.levels ? tree.off[l] : 0u;
     ta.top_rows = tree.rows[tree.levels - 1];
-    // one sweep, <= 256 tiles (every sort that takes this path by itself): the digit totals come out of the all-gather
-    const bool gather_all = !scanned && tiles <= 256u;
-    if (!scanned && !ext_hist && !gather_all) {
+    if (!scanned && !ext_hist) {
         RsHistArgs h;
         h.npasses = pl.npasses; h.radix = pl.radix; h.sub = pl.sub; h.wide = pl.depth ? t.wide : nullptr;
         for (int p = 0; p < RS_MAX_PASSES; ++p) { h.shift[p] = pl.shift[p]; h.mask[p] = (1 << pl.db[p]) - 1; }
@@ -898,7 +893,7 @@ static int rs_run(const RsPlan& pl, const RsBuffers& b, uint64_t n, void* temp, 
         RsPassArgs a;
         a.kin = kin; a.vin = vin; a.pin = pin; a.kout = kout; a.vout = vout; a.pout = pout;
         a.n = (uint32_t)n; a.n_dev = n_dev; a.shift = pl.shift[p]; a.sub = pl.sub;
-        a.hist = gather_all ? nullptr : ghist + p * hstride;
+        a.hist = ghist + p * hstride;
         a.status = t.status + (size_t)p * rs_status_rows(tiles) * pl.radix;
         a.tiles = tiles;
         // <= one workgroup per CU: the whole grid is co-resident whatever the dispatch order, so block ids are safe

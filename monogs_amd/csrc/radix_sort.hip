@@ -14,11 +14,11 @@
 //   * per pass ONE kernel: the tile publishes its 256 digit counts and obtains the sum of the counts of all EARLIER
 //     tiles by a two-level gather (its group of 16, then the group sums).
 // "Counted tiles" (> 512 k pairs; rs_scanned): per pass rs_tile_hist_kernel writes the digit counts of every tile,
-//   counts[tile][digit], and adds them into the rows of the tile's ancestors in a tree of fan-out 8 over the tiles; the
-//   scatter kernel sums the siblings before each of its ancestors (<= 7 rows per level, <= 16 at the top, all requested
+//   counts[tile][digit], and adds them into the rows of the tile's ancestors in a tree of fan-out 4 over the tiles; the
+//   scatter kernel sums the siblings before each of its ancestors (<= 3 rows per level, <= 8 at the top, all requested
 //   together before the keys: one round trip hidden behind the key loads) -- no waiting between workgroups, and no scan
-//   launch.  With hundreds of co-resident tiles the look-back's status traffic and round trips dominated the pass.
-// The last pass can also gather an auxiliary array through the sorted values (aux_out[pos] = aux_in[value]).
+//   launch.  With hundreds of co-resident tiles the status traffic and round trips of waiting dominated the pass.
+// The final pass can also gather an auxiliary array through the sorted values (aux_out[pos] = aux_in[value]).
 //
 // Ranking (round 3): rank of a pair among the pairs of its wave with the same digit = the value a returning LDS atomic
 // add on the wave's digit counter hands back -- ONE DS instruction per item.  The first version matched digits with eight
@@ -46,8 +46,8 @@
 // Inter-workgroup protocol (MI355X_MICROARCH.md "Workgroup dispatch ... visibility", form R2): every
 // status word is a self-describing 8-byte granule {flag:2, count:62} written by ONE agent-scope
 // relaxed atomic store and polled with agent-scope relaxed atomic loads; no other data crosses
-// workgroups, so no fence is needed.  Tile ids are handed out by an atomic ticket, so a tile only
-// ever waits for tiles that already started (placement-independent forward progress); every spin is
+// workgroups, so no fence is needed.  Past 256 tiles the tile ids are handed out by an atomic ticket, so a tile
+// only ever waits for tiles that already started (placement-independent forward progress); every spin is
 // bounded and raises an error flag instead of hanging.
 #include "common.h"
 
@@ -449,11 +449,11 @@ __device__ __forceinline__ void rs_digit_bases(const uint32_t (&hcount)[DPT], ui
     for (int j = 0; j < DPT; ++j) { gdigit_base[j] = run; run += hcount[j]; }
 }
 
-// one-sweep gather: adds the counts of the status rows [0, cnt) (stride `stride` words, this thread's digit) -- all of them
-// into `all`, those below `before` into `pre`.  RS_GROUP rows per batch of loads; spins (bounded) until every word of the
-// batch is published.  Returns false if it gave up.
-__device__ __forceinline__ bool rs_gather(const uint64_t* row, size_t stride, uint32_t cnt, uint32_t before,
-                                          uint32_t& pre, uint32_t& all, uint32_t& spins, uint32_t* err) {
+// one-sweep gather: adds the counts of the status rows [0, cnt) (stride `stride` words, this thread's digit) into `pre`.
+// RS_GROUP rows per batch of loads; spins (bounded) until every word of the batch is published.  Returns false if it
+// gave up.
+__device__ __forceinline__ bool rs_gather(const uint64_t* row, size_t stride, uint32_t cnt, uint32_t& pre, uint32_t& spins,
+                                          uint32_t* err) {
     constexpr uint32_t G = RS_GROUP;
     for (uint32_t r0 = 0; r0 < cnt; r0 += G) {
         uint64_t w[G];
@@ -474,11 +474,7 @@ __device__ __forceinline__ bool rs_gather(const uint64_t* row, size_t stride, ui
             }
         } while (!ready);
 #pragma unroll
-        for (uint32_t q = 0; q < G; ++q) {
-            const uint32_t c = (uint32_t)(w[q] & RS_COUNT_MASK);
-            all += c;
-            pre += (r0 + q) < before ? c : 0u;
-        }
+        for (uint32_t q = 0; q < G; ++q) pre += (uint32_t)(w[q] & RS_COUNT_MASK);
     }
     return true;
 }
@@ -712,12 +708,12 @@ __global__ void __launch_bounds__(RS_THREADS, (SCANNED && ITEMS == RS_ITEMS_WIDE
         rs_digit_bases<DPT>(hcount, gdigit_base, wsum, lane, wv);
         __hip_atomic_store(a.status + (size_t)tile * RADIX + t, RS_FLAG_LOCAL | (uint64_t)total[0], __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
-        uint32_t spins = 0, pre = 0, gpre = 0, unused = 0;
-        bool ok = rs_gather(a.status + (size_t)grp * G * RADIX + t, RADIX, jin, jin, pre, unused, spins, a.error + a.pass);
+        uint32_t spins = 0, pre = 0, gpre = 0;
+        bool ok = rs_gather(a.status + (size_t)grp * G * RADIX + t, RADIX, jin, pre, spins, a.error + a.pass);
         if (jin == members - 1)      // the group's last live tile: `pre` covers the whole group but this tile
             __hip_atomic_store(gstat + (size_t)grp * RADIX + t, RS_FLAG_GLOBAL | (uint64_t)(pre + total[0]), __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
-        if (ok) ok = rs_gather(gstat + t, RADIX, grp, grp, gpre, unused, spins, a.error + a.pass);
+        if (ok) ok = rs_gather(gstat + t, RADIX, grp, gpre, spins, a.error + a.pass);
         gbase[t] = gdigit_base[0] + gpre + pre - dbase[0];
         __syncthreads();
     }

@@ -33,8 +33,10 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec,
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=6000,
-                    help="timed steps (default: ~7 s of GPU time at N=1, longer than the 5 s period of an outside utilisation sampler)")
+    ap.add_argument("--steps", type=int, default=None,
+                    help="timed steps (default c5: 6000 = ~6 s of GPU time at N=1, longer than the 5 s period of an outside "
+                         "utilisation sampler; c4: 200 -- its steps are optimiser iterations, so a long run is a different "
+                         "map at the end than at the start)")
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--gaussians", type=int, default=2_000_000)
     ap.add_argument("--intrinsics", default="davis_1080p")
@@ -47,7 +49,10 @@ def parse():
                     help="c5: one 1080p keyframe per GPU (headline); c4: 8-keyframe Replica mapping window sharded over the GPUs")
     ap.add_argument("--window", type=int, default=8, help="c4: keyframes in the mapping window")
     ap.add_argument("--eager", action="store_true", help="c4: no hipGraph replay (every iteration launched from Python)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 6000 if args.workload == "c5" else 200
+    return args
 
 
 def self_launch(args) -> int:

@@ -125,18 +125,19 @@ int mgs_forward_render(const mgs_camera* cam, int32_t P, uint64_t num_rendered,
                        mgs_timing* timing, void* stream);
 
 /* Status word of a forward (device uint32, written by the forward's own kernels; 0 = clean).  The hand-written radix
- * sort bounds every inter-workgroup wait; a wait that runs out raises a flag instead of hanging, and the sorted order
- * (hence the blend order) is then invalid.  mgs_forward_preprocess reports a depth-sort timeout itself when it
+ * sort bounds every inter-workgroup wait (small sorts only: a tile waits for the digit counts of earlier tiles); a wait
+ * that runs out raises a flag instead of hanging, and the sorted order (hence the blend order) is then invalid.  mgs_forward_preprocess reports a depth-sort timeout itself when it
  * synchronises (num_rendered != NULL); everything else arrives here and is read by the caller at a sync point of its
  * choice (monogs_amd.rasterizer.check_overflow). */
 #define MGS_STATUS_CAPACITY_OVERFLOW 1u   /* capacity mode: instances were dropped */
-#define MGS_STATUS_DEPTH_SORT_TIMEOUT 2u  /* look-back spin of the depth sort timed out */
-#define MGS_STATUS_TILE_SORT_TIMEOUT 4u   /* look-back spin of the tile sort timed out */
+#define MGS_STATUS_DEPTH_SORT_TIMEOUT 2u  /* a bounded wait of the depth sort ran out */
+#define MGS_STATUS_TILE_SORT_TIMEOUT 4u   /* a bounded wait of the tile sort ran out */
 
-/* Test knob: the bound of the look-back spin (device-wide, all later sorts); 0xFFFFFFFF restores the default. */
+/* Test knob: the bound of those waits, in polls (device-wide, all later sorts); 0xFFFFFFFF restores the default. */
 int mgs_debug_set_radix_spin_limit(uint32_t limit);
 /* Test knobs that force an algorithm path whatever the problem size (process-wide; -1 restores the default):
- * "radix_scanned" (0 = one-sweep look-back, 1 = counted tiles), "radix_ballot_rank" (1 = rank with wave ballots instead of
+ * "radix_scanned" (0 = one kernel per pass with a gather of the earlier tiles' counts, 1 = counted tiles: two kernels per
+ * pass, no waiting between workgroups -- honoured from 64 k pairs), "radix_ballot_rank" (1 = rank with wave ballots instead of
  * returning LDS atomics: the reference the sort tests compare with), "scan_small" (0 = the two-launch scan at every size),
  * "dup_slot_major" (0 / 1 = the duplicate kernel's emission balanced by Gaussians / by output slots at every size),
  * "knn_grid_min" (Morton-box kNN from this many points).  Nothing on the launch path consults the environment. */

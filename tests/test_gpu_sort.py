@@ -114,3 +114,41 @@ def test_depths_beyond_the_narrow_range_take_the_fourth_pass(native_lib):
         native_lib.mgs_debug_set_option(b"radix_scanned", -1)
     assert torch.equal(t["point_list"], t2["point_list"]) and torch.equal(t["ranges"], t2["ranges"])
     assert torch.equal(t["perm"], t2["perm"]) and torch.equal(t["color"], t2["color"])
+
+
+def test_eight_sorts_on_eight_streams_at_once(native_lib):
+    """A mapping window sorts its keyframes at the same time, a stream each.  A tile of a small sort waits (bounded) for the
+    digit counts of EARLIER tiles only, so it makes progress whatever else occupies the chip: eight threads sort 415 k
+    five-key pairs each (203 tiles: 8 x 203 workgroups in flight, more than fit at once) and every result must be the
+    stable order, with no timeout raised."""
+    import threading
+    from monogs_amd._lib import check
+    n, bits = 415_000, 16
+    gen = torch.Generator().manual_seed(99)
+    jobs = []
+    for i in range(8):
+        keys = _keys("five" if i % 2 == 0 else "uniform", n, bits, gen).to(DEV)
+        k = keys.to(torch.int32).clone()
+        v = torch.arange(n, device=DEV, dtype=torch.int32)
+        jobs.append(dict(ref=torch.sort(keys, stable=True), k=k, v=v, ka=torch.empty_like(k), va=torch.empty_like(v),
+                         temp=torch.empty(native_lib.mgs_debug_sort_temp_bytes(n, bits), dtype=torch.uint8, device=DEV),
+                         stream=torch.cuda.Stream(), err=None))
+    torch.cuda.synchronize()
+
+    def run(j):
+        try:
+            for _ in range(4):            # (sorting sorted data again is still a full sort)
+                check(native_lib.mgs_debug_sort_pairs(j["k"].data_ptr(), j["v"].data_ptr(), j["ka"].data_ptr(), j["va"].data_ptr(),
+                                                      n, bits, j["temp"].data_ptr(), j["stream"].cuda_stream), "mgs_debug_sort_pairs")
+        except Exception as e:            # noqa: BLE001
+            j["err"] = e
+
+    threads = [threading.Thread(target=run, args=(j,)) for j in jobs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    torch.cuda.synchronize()
+    for j in jobs:
+        assert j["err"] is None, j["err"]
+        assert torch.equal(j["k"].long(), j["ref"][0]) and torch.equal(j["v"].long(), j["ref"][1])

@@ -40,25 +40,50 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t& total,
     return base + incl - v;
 }
 
-// out[i] = inclusive sum of the tiles touched by the Gaussians j <= i in depth order (rects = rect_sorted)
+// Items of a scan block are dealt out wave by wave, row by row: wave w owns items [w * 512, (w + 1) * 512) of the block, item
+// (i, lane) = i * 64 + lane of them -- every load and every store of a wave is 64 consecutive elements.  (The first version
+// gave a thread 8 CONSECUTIVE items: each of its 8 loads / stores touched all 64 lines of the wave's span an eighth each,
+// the shape that cost the per-Gaussian forward 30 us at C5.)  Row i of a wave is scanned with the DPP wave scan and
+// offset by the rows before it; the waves are joined through LDS.  Returns the block-wide total; incl[i] = inclusive sum up
+// to item (i, lane) within the block.
+__device__ __forceinline__ uint32_t scan_block_rows(const uint2* __restrict__ rects, int n, int cbase, int lane, int wv,
+                                                    uint32_t (&incl)[SCAN_PER_THREAD], uint32_t* smem /* >= 4 */) {
+    uint32_t v[SCAN_PER_THREAD];
+#pragma unroll
+    for (int i = 0; i < SCAN_PER_THREAD; ++i) {
+        const int idx = cbase + i * WAVE + lane;
+        const uint32_t wh = idx < n ? rects[idx].y : 0u;                   // tiles touched = w * h of the rectangle
+        v[i] = (wh & 0xFFFFu) * (wh >> 16);
+    }
+    uint32_t run = 0;                                                      // wave-uniform: rows before this one
+#pragma unroll
+    for (int i = 0; i < SCAN_PER_THREAD; ++i) {
+        const uint32_t sc = wave_incl_scan_dpp(v[i]);
+        incl[i] = run + sc;
+        run += (uint32_t)__builtin_amdgcn_readlane((int)sc, 63);
+    }
+    if (lane == 0) smem[wv] = run;
+    __syncthreads();
+    uint32_t wbase = 0;
+    for (int w = 0; w < wv; ++w) wbase += smem[w];
+    const uint32_t total = (smem[0] + smem[1]) + (smem[2] + smem[3]);
+#pragma unroll
+    for (int i = 0; i < SCAN_PER_THREAD; ++i) incl[i] += wbase;
+    return total;
+}
+
+// out[i] = inclusive sum of the tiles touched by the Gaussians j <= i in depth order (rects = rect_sorted), within the block
 __global__ void __launch_bounds__(SCAN_THREADS) scan_local_kernel(const uint2* __restrict__ rects, uint32_t* out,
                                                                   uint32_t* block_sums, int n) {
     __shared__ uint32_t smem[8];
-    const int base = blockIdx.x * SCAN_ITEMS + threadIdx.x * SCAN_PER_THREAD;
-    uint32_t v[SCAN_PER_THREAD];
-    uint32_t sum = 0;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int cbase = blockIdx.x * SCAN_ITEMS + wv * (SCAN_PER_THREAD * WAVE);
+    uint32_t incl[SCAN_PER_THREAD];
+    const uint32_t total = scan_block_rows(rects, n, cbase, lane, wv, incl, smem);
 #pragma unroll
     for (int i = 0; i < SCAN_PER_THREAD; ++i) {
-        const uint32_t wh = (base + i < n) ? rects[base + i].y : 0u;      // tiles touched = w * h of the rectangle
-        v[i] = (wh & 0xFFFFu) * (wh >> 16);
-        sum += v[i];
-    }
-    uint32_t total;
-    uint32_t run = block_excl_scan(sum, total, smem);
-#pragma unroll
-    for (int i = 0; i < SCAN_PER_THREAD; ++i) {
-        run += v[i];
-        if (base + i < n) out[base + i] = run;
+        const int idx = cbase + i * WAVE + lane;
+        if (idx < n) out[idx] = incl[i];
     }
     if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
 }
@@ -90,17 +115,10 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_small_kernel(const uint2* _
                                                                   uint32_t* err) {
     __shared__ uint32_t smem[8];
     __shared__ uint32_t s_prefix;
-    const int base = blockIdx.x * SCAN_ITEMS + threadIdx.x * SCAN_PER_THREAD;
-    uint32_t v[SCAN_PER_THREAD];
-    uint32_t sum = 0;
-#pragma unroll
-    for (int i = 0; i < SCAN_PER_THREAD; ++i) {
-        const uint32_t wh = (base + i < n) ? rects[base + i].y : 0u;
-        v[i] = (wh & 0xFFFFu) * (wh >> 16);
-        sum += v[i];
-    }
-    uint32_t total;
-    uint32_t run = block_excl_scan(sum, total, smem);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int cbase = blockIdx.x * SCAN_ITEMS + wv * (SCAN_PER_THREAD * WAVE);
+    uint32_t incl[SCAN_PER_THREAD];
+    const uint32_t total = scan_block_rows(rects, n, cbase, lane, wv, incl, smem);
     if (threadIdx.x == 0)
         __hip_atomic_store(status + blockIdx.x, (1ull << 63) | (uint64_t)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (threadIdx.x < WAVE) {
@@ -121,11 +139,10 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_small_kernel(const uint2* _
         if (threadIdx.x == 0) s_prefix = before;
     }
     __syncthreads();
-    run += s_prefix;
 #pragma unroll
     for (int i = 0; i < SCAN_PER_THREAD; ++i) {
-        run += v[i];
-        if (base + i < n) out[base + i] = run;
+        const int idx = cbase + i * WAVE + lane;
+        if (idx < n) out[idx] = incl[i] + s_prefix;
     }
     if (threadIdx.x == 0 && (int)blockIdx.x == nb - 1) block_sums[nb] = s_prefix + total;
 }

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define MGS_ABI_VERSION 7
+#define MGS_ABI_VERSION 8
 #define MGS_TILE 16 /* tile edge in pixels; ranges are per 16x16 tile */
 
 /* GaussianRasterizationSettings, minus `prefiltered` / `debug` which are call flags
@@ -55,12 +55,23 @@ typedef struct mgs_camera {
                                     the expansion render() does with scales.repeat(1, 3)
                                     (/root/reference/gaussian_splatting/gaussian_renderer/__init__.py:101-104) and the
                                     sum of its backward happen inside the kernels */
+    int32_t flags;               /* MGS_FLAG_* bits, 0 = none */
     const float* bg;             /* [3]  */
     const float* viewmatrix;     /* [16] transposed world->camera */
     const float* projmatrix;     /* [16] transposed P @ T_cw */
     const float* projmatrix_raw; /* [16] transposed P */
     const float* campos;         /* [3]  */
 } mgs_camera;
+
+/* mgs_camera.flags.
+ * MGS_FLAG_EXCLUSIVE_DEVICE: the caller guarantees that NO other grid runs beside this call's kernels -- one process on the
+ * device, one stream (a pose-tracking loop, a captured single-stream iteration).  The small radix sorts (<= 256 tiles) then
+ * take their tile ids from the block index, which saves a returning atomic (~2 us) per pass.  Without the flag -- the
+ * default, and what MonoGS's topology needs: tracker, mapper and viewer processes share one GPU
+ * (/root/reference/slam.py:102-179), and a mapping window renders its keyframes on a stream each -- every sort hands out
+ * tile ids by an atomic ticket, so a tile only ever waits for tiles that have already started: forward progress does not
+ * depend on where, or in which order, the hardware places workgroups of competing grids. */
+#define MGS_FLAG_EXCLUSIVE_DEVICE 1
 
 /* Per-stage device time in milliseconds, measured with HIP events on `stream`.
  * Passing a non-NULL mgs_timing makes the call synchronise `stream` before returning. */
@@ -79,8 +90,19 @@ typedef struct mgs_timing {
 int mgs_abi_version(void);
 const char* mgs_last_error(void);
 
+/* Largest map one call takes.  The blend backward addresses a Gaussian's 64-byte gradient line with a 32-bit byte offset
+ * (index x 64 + slot), which wraps at 2^26 Gaussians; the entry points that take P return 1 ("P exceeds ...") beyond it
+ * instead of wrapping.  (A 288 GB device could hold such a map; MonoGS maps are 10^4 .. 10^6.) */
+#define MGS_MAX_GAUSSIANS ((1 << 26) - 1)
+
 /* Scratch sizes (bytes).  geometry: per-Gaussian state carried from forward to backward;
- * image: per-pixel and per-tile state; binning: keys / values / sort temp for R = num_rendered. */
+ * image: per-pixel and per-tile state; binning: keys / values / sort temp for R = num_rendered.
+ * LIFETIME (caller-owned, the library keeps nothing): geometry, image, binning and the backward scratch must stay
+ * allocated and unmodified from the forward until the LAST backward through it has run; radii / n_touched / the three
+ * images are plain outputs and need not outlive anything.  The Python binding (monogs_amd/rasterizer.py) carries the
+ * scratch in the autograd context -- about 250 B per Gaussian + 8 B per pixel + 16 B per instance, alive exactly as long as
+ * the graph of that forward -- and hands out radii / n_touched as views of their own 8 P-byte tensor and the images as views
+ * of one 20 HW-byte tensor, so keeping an OUTPUT (render_pkg["radii"], a keyframe's n_touched) never pins the scratch. */
 size_t mgs_geometry_bytes(int32_t P);
 size_t mgs_image_bytes(int32_t width, int32_t height);
 size_t mgs_binning_bytes(uint64_t num_rendered, int32_t width, int32_t height);

@@ -11,7 +11,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MGS_LIB_PATH") or os.path.join(_HERE, "lib", "libmonogs_raster.so")   # (override: kernel experiments)
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 c_float_p = C.c_void_p   # device pointers travel as integers (tensor.data_ptr())
 
@@ -20,7 +20,7 @@ class MgsCamera(C.Structure):
     _fields_ = [
         ("image_height", C.c_int32), ("image_width", C.c_int32),
         ("tanfovx", C.c_float), ("tanfovy", C.c_float), ("scale_modifier", C.c_float),
-        ("sh_degree", C.c_int32), ("sh_coeffs", C.c_int32), ("scale_dim", C.c_int32),
+        ("sh_degree", C.c_int32), ("sh_coeffs", C.c_int32), ("scale_dim", C.c_int32), ("flags", C.c_int32),
         ("bg", C.c_void_p), ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p),
         ("projmatrix_raw", C.c_void_p), ("campos", C.c_void_p),
     ]

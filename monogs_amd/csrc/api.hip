@@ -119,6 +119,15 @@ static int check_cam(const mgs_camera* cam) {
     return 0;
 }
 
+// the blend backward forms `index * 64 + slot` in 32 bits (blend.hip, bt_flush): refuse maps it cannot address
+static int check_map_size(int32_t P) {
+    if (P > MGS_MAX_GAUSSIANS) {
+        set_error("P exceeds MGS_MAX_GAUSSIANS (2^26 - 1): the gradient-line offset of the blend backward is 32-bit");
+        return 1;
+    }
+    return 0;
+}
+
 }  // namespace mgs
 
 using namespace mgs;
@@ -143,6 +152,7 @@ int mgs_forward_preprocess(const mgs_camera* cam, int32_t P, const float* means3
                            uint32_t* prev_status_out, mgs_timing* timing, void* stream) {
     if (check_cam(cam)) return 1;
     if (P < 0) { set_error("P must be >= 0"); return 1; }
+    if (check_map_size(P)) return 1;
     if (num_rendered) *num_rendered = 0;        // NULL = capacity mode: no read-back, no stream sync
     if (prev_status_out) *prev_status_out = 0;
     if (P == 0) {
@@ -174,7 +184,8 @@ int mgs_forward_preprocess(const mgs_camera* cam, int32_t P, const float* means3
                                            cov3D_precomp, g, radii,
                                            prepare_backward ? backward_grad_acc(prepare_backward) : nullptr, s)) return rc;
     tm.mark();
-    if (int rc = launch_depth_sort(g, P, depth_sort_payload(P, cam->image_width, cam->image_height), s)) return rc;
+    const bool exclusive = (cam->flags & MGS_FLAG_EXCLUSIVE_DEVICE) != 0;
+    if (int rc = launch_depth_sort(g, P, depth_sort_payload(P, cam->image_width, cam->image_height), s, exclusive)) return rc;
     tm.mark();
     if (int rc = launch_scan(g, P, s)) return rc;
     tm.mark();
@@ -204,6 +215,8 @@ static int forward_render_impl(const mgs_camera* cam, int32_t P, uint64_t R, boo
                                void* binning, void* image, float* out_color, float* out_depth, float* out_opacity,
                                int32_t* n_touched, uint32_t* overflow, mgs_timing* timing, void* stream) {
     if (check_cam(cam)) return 1;
+    if (P < 0) { set_error("P must be >= 0"); return 1; }
+    if (check_map_size(P)) return 1;
     if (!image || !out_color || !out_depth || !out_opacity) { set_error("image scratch and outputs must be non-NULL"); return 1; }
     if (P > 0 && (!geometry || !n_touched)) { set_error("geometry and n_touched must be non-NULL"); return 1; }
     if (R > 0 && !binning) { set_error("binning scratch is NULL"); return 1; }
@@ -226,7 +239,7 @@ static int forward_render_impl(const mgs_camera* cam, int32_t P, uint64_t R, boo
     if (int rc = launch_duplicate(*cam, P, g, b, capacity ? R : (R > 0 ? 0xFFFFFFFFull : 0ull), n_touched, img, R,
                                   tile_bits(W, H), cap ? b.count : nullptr, overflow, s)) return rc;
     tm.mark();
-    if (int rc = launch_sort(g, b, R, tile_bits(W, H), s, n_dev)) return rc;
+    if (int rc = launch_sort(g, b, R, tile_bits(W, H), s, n_dev, (cam->flags & MGS_FLAG_EXCLUSIVE_DEVICE) != 0)) return rc;
     tm.mark();
     if (int rc = launch_ranges(b, R, img, tiles_x(W) * tiles_y(H), tile_bits(W, H), s, n_dev, overflow)) return rc;
     tm.mark();
@@ -276,6 +289,8 @@ int mgs_backward(const mgs_camera* cam, int32_t P, uint64_t R, const float* mean
                  float* dL_dscales, float* dL_drotations, float* dL_dtau, void* backward_scratch,
                  int32_t scratch_prepared, mgs_timing* timing, void* stream) {
     if (check_cam(cam)) return 1;
+    if (P < 0) { set_error("P must be >= 0"); return 1; }
+    if (check_map_size(P)) return 1;
     hipStream_t s = (hipStream_t)stream;
     if (P == 0) {
         if (dL_dtau) MGS_HIP(zero_fill(dL_dtau, 6 * sizeof(float), s));

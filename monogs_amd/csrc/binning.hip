@@ -417,20 +417,21 @@ int launch_duplicate(const mgs_camera& cam, int P, const GeometryState& g, const
 // ------------------------------------------------------------------------------------------------
 size_t sort_temp_bytes(uint64_t n, int bits) { return radix_temp_bytes(n, bits); }
 
-int launch_depth_sort(const GeometryState& g, int P, bool payload, hipStream_t s) {
+int launch_depth_sort(const GeometryState& g, int P, bool payload, hipStream_t s, bool exclusive) {
     // the scratch was cleared by preprocess_forward_kernel; the final pass also lays the tile rectangles out in depth
     // order for the scan and duplicate (`payload`: they travelled with the pairs, else it gathers them)
     return radix_sort_depth(g.depth_key, g.depth_alt, g.iota, g.iota_alt, g.rect, payload, g.perm, g.rect_sorted, (uint64_t)P,
-                            g.sort_temp, s, true);
+                            g.sort_temp, s, true, exclusive);
 }
 
-int launch_sort(const GeometryState& g, const BinningState& b, uint64_t R, int bits, hipStream_t s, const uint32_t* n_dev) {
+int launch_sort(const GeometryState& g, const BinningState& b, uint64_t R, int bits, hipStream_t s, const uint32_t* n_dev,
+                bool exclusive) {
     if (R == 0) return 0;
     // the scratch was cleared by duplicate_kernel, which also counted the digits of the keys it emitted (small sorts; the
     // same predicate as launch_duplicate's `count_digits` -- R > 0 implies P > 0, forward_render_impl)
     const bool counted = bits <= 16 && radix_wants_hist(R) && g.tile_hist != nullptr;
     return radix_sort_pairs(b.keys_a, b.vals_a, b.keys_b, b.vals_b, R, bits, b.sort_temp, s, n_dev, true, nullptr, nullptr,
-                            counted ? g.tile_hist : nullptr);
+                            counted ? g.tile_hist : nullptr, false, exclusive);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -224,18 +224,20 @@ int radix_sort_pairs(uint32_t* ka, uint32_t* va, uint32_t* kb, uint32_t* vb, uin
                      hipStream_t s, const uint32_t* n_dev = nullptr, bool temp_zeroed = false,
                      const uint2* aux_in = nullptr, uint2* aux_out = nullptr,   // last pass also writes aux_out[i] = aux_in[value i]
                      const uint32_t* ext_hist = nullptr,
-                     bool aux_empty_for_ones = false);       // a key of all ones gets aux (0, 0) without the fetch
+                     bool aux_empty_for_ones = false,        // a key of all ones gets aux (0, 0) without the fetch
+                     bool exclusive = false);                // MGS_FLAG_EXCLUSIVE_DEVICE: small sorts may use block ids as tile ids
 bool radix_wants_hist(uint64_t n);
 // The forward's first sort (radix_sort.hip): depth keys -> perm + rect_sorted; three 9-bit passes (+ a fourth that only
 // runs for depths beyond 13 107 units).  radix_depth_payload(n): the sort carries the packed rectangles itself.
 bool radix_depth_payload(uint64_t n);
 int radix_sort_depth(uint32_t* keys, uint32_t* key_b, uint32_t* val_a, uint32_t* val_b, void* rect, bool payload,
-                     uint32_t* perm, uint2* rect_sorted, uint64_t n, void* temp, hipStream_t s, bool temp_zeroed);
+                     uint32_t* perm, uint2* rect_sorted, uint64_t n, void* temp, hipStream_t s, bool temp_zeroed,
+                     bool exclusive = false);
 // the packed form needs both tile-grid dimensions to fit a byte
 inline bool depth_sort_payload(int P, int W, int H) { return radix_depth_payload((uint64_t)P) && tiles_x(W) <= 255 && tiles_y(H) <= 255; }
-int launch_depth_sort(const GeometryState& g, int P, bool payload, hipStream_t s);
+int launch_depth_sort(const GeometryState& g, int P, bool payload, hipStream_t s, bool exclusive = false);
 int launch_sort(const GeometryState& g, const BinningState& b, uint64_t R, int bits, hipStream_t s,
-                const uint32_t* n_dev = nullptr);
+                const uint32_t* n_dev = nullptr, bool exclusive = false);
 int launch_ranges(const BinningState& b, uint64_t R, const ImageState& img, int ntiles, int sort_bits, hipStream_t s,
                   const uint32_t* n_dev = nullptr, uint32_t* status = nullptr);
 int set_radix_spin_limit(uint32_t limit);

@@ -46,9 +46,9 @@
 // Inter-workgroup protocol (MI355X_MICROARCH.md "Workgroup dispatch ... visibility", form R2): every
 // status word is a self-describing 8-byte granule {flag:2, count:62} written by ONE agent-scope
 // relaxed atomic store and polled with agent-scope relaxed atomic loads; no other data crosses
-// workgroups, so no fence is needed.  Past 256 tiles the tile ids are handed out by an atomic ticket, so a tile
-// only ever waits for tiles that already started (placement-independent forward progress); every spin is
-// bounded and raises an error flag instead of hanging.
+// workgroups, so no fence is needed.  The tile ids are handed out by an atomic ticket, so a tile only ever waits for
+// tiles that already started (placement-independent forward progress; block ids only for <= 256 tiles on a device the
+// caller declares exclusive, see rs_run); every spin is bounded and raises an error flag instead of hanging.
 #include "common.h"
 
 namespace mgs {
@@ -859,7 +859,7 @@ struct RsBuffers {
     bool aux_skip_ones;
 };
 static int rs_run(const RsPlan& pl, const RsBuffers& b, uint64_t n, void* temp, hipStream_t s, const uint32_t* n_dev,
-                  bool temp_zeroed, const uint32_t* ext_hist) {
+                  bool temp_zeroed, const uint32_t* ext_hist, bool exclusive) {
     if (n == 0) return 0;
     if (n >= (1ull << 32)) { set_error("radix sort: more than 2^32-1 pairs"); return 1; }
     const bool scanned = rs_scanned(n);
@@ -892,8 +892,13 @@ static int rs_run(const RsPlan& pl, const RsBuffers& b, uint64_t n, void* temp, 
         a.hist = ghist + p * hstride;
         a.status = t.status + (size_t)p * rs_status_rows(tiles) * pl.radix;
         a.tiles = tiles;
-        // <= one workgroup per CU: the whole grid is co-resident whatever the dispatch order, so block ids are safe
-        a.ticket = tiles <= 256u ? nullptr : t.tickets + p;
+        // Tile ids come from an atomic ticket: a tile then only waits for tiles that have STARTED, whatever order and place
+        // the hardware gives the workgroups of this grid and of the grids running beside it (a mapping window's keyframes
+        // sort on a stream each, MonoGS's three processes share the device; workgroups are dealt round-robin to per-XCD
+        // dispatchers, so a higher block id can be resident and spinning while a lower one waits for a slot on a full XCD).
+        // Only a caller that vouches for an otherwise idle device (MGS_FLAG_EXCLUSIVE_DEVICE) gets block ids for grids of at
+        // most one workgroup per CU -- those are co-resident whatever the dispatch order -- and saves the atomic's round trip.
+        a.ticket = (exclusive && tiles <= 256u) ? nullptr : t.tickets + p;
         a.error = t.error;
         a.pass = p;
         a.counts = t.counts; a.sums = t.sums + (size_t)p * tree.sum_rows * pl.radix;
@@ -935,13 +940,13 @@ static int rs_run(const RsPlan& pl, const RsBuffers& b, uint64_t n, void* temp, 
 
 int radix_sort_pairs(uint32_t* ka, uint32_t* va, uint32_t* kb, uint32_t* vb, uint64_t n, int bits, void* temp,
                      hipStream_t s, const uint32_t* n_dev, bool temp_zeroed, const uint2* aux_in, uint2* aux_out,
-                     const uint32_t* ext_hist, bool aux_empty_for_ones) {
+                     const uint32_t* ext_hist, bool aux_empty_for_ones, bool exclusive) {
     const RsPlan pl = rs_plan_plain(bits);
     if (pl.npasses > RS_MAX_PASSES) { set_error("radix sort: more than 32 key bits"); return 1; }
     RsBuffers b;
     b.ka = ka; b.va = va; b.va_is_index = false; b.pa = nullptr; b.kb = kb; b.vb = vb; b.pb = nullptr; b.kfinal = nullptr; b.vfinal = nullptr;
     b.aux_in = aux_in; b.aux_out = aux_out; b.aux_skip_ones = aux_empty_for_ones;
-    return rs_run(pl, b, n, temp, s, n_dev, temp_zeroed, ext_hist);
+    return rs_run(pl, b, n, temp, s, n_dev, temp_zeroed, ext_hist, exclusive);
 }
 
 // The depth sort of the forward (see the header): keys[P] = float bits of the depths (all ones: culled), destroyed;
@@ -949,14 +954,14 @@ int radix_sort_pairs(uint32_t* ka, uint32_t* va, uint32_t* kb, uint32_t* vb, uin
 // uint2[P] (gathered by the final pass) or, with `payload`, uint32[2 P]: the packed rectangles in the first half, the
 // second half their ping-pong partner.  val_a / val_b and key_b: P words each of scratch.
 int radix_sort_depth(uint32_t* keys, uint32_t* key_b, uint32_t* val_a, uint32_t* val_b, void* rect, bool payload,
-                     uint32_t* perm, uint2* rect_sorted, uint64_t n, void* temp, hipStream_t s, bool temp_zeroed) {
+                     uint32_t* perm, uint2* rect_sorted, uint64_t n, void* temp, hipStream_t s, bool temp_zeroed, bool exclusive) {
     const RsPlan pl = rs_plan_for_depth(n);
     RsBuffers b;
     b.ka = keys; b.va = val_a; b.va_is_index = true; b.kb = key_b; b.vb = val_b;
     b.pa = payload ? (uint32_t*)rect : nullptr; b.pb = payload ? (uint32_t*)rect + n : nullptr;
     b.kfinal = nullptr; b.vfinal = perm;
     b.aux_in = payload ? nullptr : (const uint2*)rect; b.aux_out = rect_sorted; b.aux_skip_ones = true;
-    return rs_run(pl, b, n, temp, s, nullptr, temp_zeroed, nullptr);
+    return rs_run(pl, b, n, temp, s, nullptr, temp_zeroed, nullptr, exclusive);
 }
 
 int set_radix_spin_limit(uint32_t limit) {

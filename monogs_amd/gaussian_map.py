@@ -70,6 +70,7 @@ class GaussianMap:
         self.nr_obs = torch.empty(0, dtype=torch.int32, device=device)
         # position learning-rate schedule (update_learning_rate, gaussian_model.py:451-465); off unless configured
         self.lr_schedule = None             # dict(lr_init, lr_final, lr_delay_mult, max_steps)
+        self.surgery_log = None             # a list: densify_and_prune appends the map sizes around each of its steps
 
     get_xyz = property(lambda s: s._xyz)
     get_features = property(lambda s: s._rgb)
@@ -175,12 +176,17 @@ class GaussianMap:
     def densify_and_prune(self, max_grad, min_opacity, extent, max_screen_size, generator=None):
         grads = self.xyz_gradient_accum / self.denom
         grads[grads.isnan()] = 0.0
+        n0 = len(self)
         self.densify_and_clone(grads, max_grad, extent)
+        n1 = len(self)
         self.densify_and_split(grads, max_grad, extent, generator=generator)
+        n2 = len(self)
         prune = (self.get_opacity < min_opacity).squeeze(1)
         if max_screen_size:
             prune = prune | (self.max_radii_2d > max_screen_size) | (self.get_scaling.max(dim=1).values > 0.1 * extent)
         self.prune_points(prune)
+        if self.surgery_log is not None:     # (map sizes only: no extra device work, the lengths are host integers)
+            self.surgery_log.append(dict(before=n0, cloned=n1 - n0, split_net=n2 - n1, pruned=n2 - len(self), after=len(self)))
 
     def add_densification_stats(self, viewspace_point_tensor, radii):
         """One rendered keyframe: ``xyz_gradient_accum`` / ``denom`` (gaussian_model.py:888-892) and ``max_radii_2d``
@@ -221,13 +227,15 @@ class GaussianMap:
     def extend_from_frame(self, vp, intr, downsample: int, point_size=0.05, init=False, render_opacity=None,
                           render_depth=None, kf_id: Optional[int] = None):
         """Back-project a keyframe's depth into new Gaussians; scale from distCUDA2
-        (gaussian_model.py:121-319 via ``monogs_amd.keyframe``)."""
+        (gaussian_model.py:121-319 via ``monogs_amd.keyframe``).  ``point_size=None``: the reference's rule,
+        scale^2 = dist2 x min(0.05, 0.01 x median depth) (gaussian_model.py:173-178); a number: scale^2 = dist2 x point_size."""
         from .keyframe import create_viewpoint_pcd
         g = torch.Generator(device=self.device).manual_seed(1000 + vp.frame_idx)
+        ps = dict(point_size=0.01, point_size_max=0.05) if point_size is None else dict(point_size=1e9, point_size_max=point_size)
         pw, rgb, scales, rots, opac, _ = create_viewpoint_pcd(
             vp, intr, render_depth=None if init else (render_depth if render_depth is not None else vp.depth),
             render_opacity=None if init else render_opacity, init=init,
-            generator=g, downsample_factor=downsample, point_size=1e9, point_size_max=point_size)   # scale^2 = dist2 * point_size
+            generator=g, downsample_factor=downsample, **ps)
         n_new = pw.shape[0]
         if n_new < 4:
             return 0

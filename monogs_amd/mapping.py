@@ -142,6 +142,7 @@ class WindowMapper:
         self._pool = None
         self.stats = dict(captures=0, replays=0, eager_iters=0, capture_s=0.0, replay_s=0.0, replay_kf=0)
         self.time_replays = False        # measure the replay chunks (one synchronisation at either end of a chunk)
+        self.coviz_log: List = []        # (map size, Gaussians dropped) of every covisibility prune
 
     # ---- per-keyframe optimiser state lives on the owning rank ------------------------------------------------------
     def _pose_optimizer(self, vp) -> PoseAdam:
@@ -506,8 +507,13 @@ class WindowMapper:
         self._exchange(p, grads=False)
         self._materialise_visibility(kf_ids)
         if len(viewpoints) == self.window_size:
+            # prune_points replaces every Gaussian tensor by a new leaf, so the Gaussian gradients of this call vanish with the
+            # old ones; nothing touches the keyframes' pose / exposure .grad, which the reference returns with (no zero_grad on
+            # this path, slam_mapper.py:408-451): the next call's first backward adds to them, as in the other branch
             self._carry = None
-            self._zero_grads(p, viewpoints)
+            self.gmap.optimizer.zero_grad(set_to_none=True)
+            for h in p.holders:
+                h.grad = None
             self._prune_covisibility(kf_ids)
         else:
             # (the pose / exposure gradients of the owned keyframes stay in their .grad, as in the reference; the next
@@ -539,7 +545,9 @@ class WindowMapper:
         else:
             kf_mask = gmap.kf_idx >= sorted(kf_ids, reverse=True)[2]
         to_prune = (gmap.nr_obs <= self.prune_coviz) & kf_mask
+        n0 = len(gmap)
         gmap.prune_points(to_prune)
+        self.coviz_log.append((n0, n0 - len(gmap)))
         keep = ~to_prune
         self.occ_aware_visibility = {k: v[keep] for k, v in self.occ_aware_visibility.items()}
         self._drop_plan()

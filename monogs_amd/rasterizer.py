@@ -55,7 +55,8 @@ class _State:
     capacity_hint: dict = {}
     pending: list = []            # (key, flag) of capacity-mode forwards not yet checked
     graph: list = []              # flags of forwards recorded inside a hipGraph capture: re-checked on every call
-    exact_pending = None          # (key, flag) of the last exact forward, or None
+    exact_pending = None          # (key, flag, device index, raw stream) of the last exact forward, or None
+    exact_other: list = []        # the same of exact forwards whose successor ran on ANOTHER stream: only check_overflow() reads them
     exact_failed = 0              # status bits collected from earlier exact forwards, raised by the next forward / check
 
 
@@ -75,6 +76,26 @@ def set_sync_free(enabled: bool, headroom: float = 1.5):
     _sync_free["enabled"], _sync_free["headroom"] = bool(enabled), float(headroom)
 
 
+def sync_free_enabled() -> bool:
+    return bool(_sync_free["enabled"])
+
+
+# MGS_FLAG_EXCLUSIVE_DEVICE (include/monogs_raster.h): the caller vouches that nothing else runs on the device beside the
+# forwards issued while this is on -- one process, one stream.  Off by default: MonoGS shares one GPU between three processes.
+_call_flags = {"exclusive": False}
+
+
+@contextlib.contextmanager
+def exclusive_device(on: bool = True):
+    """``with exclusive_device():`` forwards issued (or captured) inside may assume an otherwise idle device: the small radix
+    sorts skip their ticket atomics.  For single-stream loops of a process that owns the GPU (the harness's tracking replays)."""
+    prev, _call_flags["exclusive"] = _call_flags["exclusive"], bool(on)
+    try:
+        yield
+    finally:
+        _call_flags["exclusive"] = prev
+
+
 STATUS_CAPACITY_OVERFLOW, STATUS_DEPTH_SORT_TIMEOUT, STATUS_TILE_SORT_TIMEOUT = 1, 2, 4     # MGS_STATUS_* (monogs_raster.h)
 
 
@@ -91,8 +112,14 @@ def check_overflow() -> bool:
     and gradients, are invalid."""
     hit, sort_fail = False, _State.exact_failed
     _State.exact_failed = 0
-    todo = _State.pending + _State.graph + ([_State.exact_pending] if _State.exact_pending is not None else [])
+    exact = _State.exact_other + ([_State.exact_pending] if _State.exact_pending is not None else [])
     _State.exact_pending = None
+    _State.exact_other = []
+    # a status word is written by its forward's kernels on the stream (and device) that forward ran on; `.item()` only waits
+    # for the CURRENT stream, so drain the devices involved first
+    for d in {e[2] for e in exact} | {f.device.index for _, f in _State.pending + _State.graph}:
+        torch.cuda.synchronize(d)
+    todo = _State.pending + _State.graph + [(e[0], e[1]) for e in exact]
     for key, flag in todo:
         v = int(flag.item())
         if v & STATUS_CAPACITY_OVERFLOW:
@@ -146,6 +173,7 @@ def _f32(t: torch.Tensor, name: str) -> torch.Tensor:
 def _camera(rs: GaussianRasterizationSettings, sh_coeffs: int, keep: list, scale_dim: int = 3) -> _lib.MgsCamera:
     cam = _lib.MgsCamera()
     cam.scale_dim = int(scale_dim)
+    cam.flags = 1 if _call_flags["exclusive"] else 0            # MGS_FLAG_EXCLUSIVE_DEVICE
     cam.image_height, cam.image_width = int(rs.image_height), int(rs.image_width)
     cam.tanfovx, cam.tanfovy = float(rs.tanfovx), float(rs.tanfovy)
     cam.scale_modifier = float(rs.scale_modifier)
@@ -220,24 +248,27 @@ class _RasterizeGaussians(torch.autograd.Function):
             timing = _lib.MgsTiming() if _timing_sink is not None else None
             tref = C.byref(timing) if timing is not None else None
             u8 = dict(dtype=torch.uint8, device=dev)
-            # ONE allocation for everything the backward needs back (geometry + image scratch, radii, n_touched and the
-            # scratch of the backward itself) and one for the three images: ten torch.empty per forward were ~35 us of host
-            # time at SLAM sizes.  radii / n_touched / the images are views; the scratch parts travel as raw addresses.
+            # ONE allocation for everything the backward needs back (geometry + image scratch and the scratch of the backward
+            # itself), one for the three images and one for the two per-Gaussian integer results: ten torch.empty per forward
+            # were ~35 us of host time at SLAM sizes.  LIFETIME: the arena (~250 B per Gaussian + 8 B per pixel) lives as long as
+            # the autograd graph of this forward (it is what the backward reads) -- not as long as any OUTPUT: `radii` and
+            # `n_touched` are views of their own 8 P-byte tensor, which a caller may keep (WindowMapper does, per keyframe;
+            # MonoGS keeps `radii` in render_pkg) without pinning the scratch.  The three images share one 20 HW-byte tensor.
             want_bwd = P > 0 and any(ctx.needs_input_grad)
             n_geom, n_img = _al(lib.mgs_geometry_bytes(P)), _al(lib.mgs_image_bytes(W, H))
-            n_ri, n_bwd = _al(4 * P), (_al(lib.mgs_backward_bytes(P)) if want_bwd else 0)
-            arena = torch.empty(n_geom + n_img + 2 * n_ri + n_bwd + 256, **u8)
+            n_bwd = _al(lib.mgs_backward_bytes(P)) if want_bwd else 0
+            arena = torch.empty(n_geom + n_img + n_bwd + 256, **u8)
             base = arena.data_ptr()
             off0 = (-base) % 256                                    # the carving functions expect 256-byte-aligned bases
             geom_p, img_p = base + off0, base + off0 + n_geom
             o_r = off0 + n_geom + n_img
-            radii = arena[o_r:o_r + 4 * P].view(torch.int32)
-            n_touched = arena[o_r + n_ri:o_r + n_ri + 4 * P].view(torch.int32)
+            ri = torch.empty(2, P, dtype=torch.int32, device=dev)
+            radii, n_touched = ri[0], ri[1]
             # The scratch of the backward that will follow is handed to the forward: its per-Gaussian kernel clears the
             # gradient lines of the visible Gaussians (and the pose part) on the way, and the backward starts with no
             # clearing launch and no 64 B x P fill.
-            ctx.scratch = arena[o_r + 2 * n_ri:o_r + 2 * n_ri + n_bwd] if want_bwd else None
-            bwd_p = base + o_r + 2 * n_ri if want_bwd else None
+            ctx.scratch = arena[o_r:o_r + n_bwd] if want_bwd else None
+            bwd_p = base + o_r if want_bwd else None
             ctx.scratch_used = False
             out5 = torch.empty(5, H, W, dtype=torch.float32, device=dev)
             color, depth, opacity = out5[0:3], out5[3:4], out5[4:5]
@@ -266,6 +297,14 @@ class _RasterizeGaussians(torch.autograd.Function):
             else:
                 num_rendered, prev_bits = C.c_uint64(0), C.c_uint32(0)
                 prev = _State.exact_pending
+                here = (torch._C._cuda_getDevice(), _stream())
+                if prev is not None and (prev[2], prev[3]) != here:
+                    # the earlier forward ran on another stream / device: this stream's read-back is not ordered behind its
+                    # kernels (the header's contract is "an EARLIER forward on this stream"), so its word waits for check_overflow()
+                    _State.exact_other.append(prev)
+                    if len(_State.exact_other) > PENDING_MAX:
+                        del _State.exact_other[:PENDING_MAX // 2]
+                    prev = None
                 _lib.check(lib.mgs_forward_preprocess(
                     C.byref(cam), P, _ptr(means3D), _ptr(sh_), _ptr(col_), _ptr(opac_), _ptr(sc_), _ptr(rot_),
                     _ptr(cov_), geom_p, radii.data_ptr(), bwd_p, C.byref(num_rendered),
@@ -282,7 +321,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                     depth.data_ptr(), opacity.data_ptr(), n_touched.data_ptr(), _ptr(status), tref, _stream()),
                     "mgs_forward_render")
                 if status is not None:      # (the depth sort's flag was already checked at the count read-back)
-                    _State.exact_pending = (key, status)
+                    _State.exact_pending = (key, status, here[0], here[1])
                 ctx.overflow = None
             if rs.debug:                    # upstream's debug flag: synchronise and check right after the forward
                 check_overflow()

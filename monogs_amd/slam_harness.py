@@ -44,6 +44,22 @@ class Intrinsics:
         self.FoVx, self.FoVy = 2 * math.atan(m.tanfovx), 2 * math.atan(m.tanfovy)
 
 
+def scharr_grad_mask(rgb: torch.Tensor, edge_threshold: float = 1.1, eps: float = 0.01) -> torch.Tensor:
+    """``CameraExtrinsics.compute_grad_mask`` (/root/reference/utils/camera_utils.py:185-216): Scharr gradient of the grey
+    image (``image_gradient``, utils/slam_utils.py:6-23: reflect padding, normalised by 32), zeroed where a 3x3
+    neighbourhood holds a pixel <= ``eps`` (``image_gradient_mask``, :26-40), thresholded at ``edge_threshold`` x median."""
+    gray = rgb.mean(dim=0, keepdim=True)
+    kx = torch.tensor([[3.0, 10.0, 3.0], [0.0, 0.0, 0.0], [-3.0, -10.0, -3.0]], device=rgb.device)
+    ky = torch.tensor([[3.0, 0.0, -3.0], [10.0, 0.0, -10.0], [3.0, 0.0, -3.0]], device=rgb.device)
+    pad = torch.nn.functional.pad(gray[None], (1, 1, 1, 1), mode="reflect")
+    conv = torch.nn.functional.conv2d
+    gv = conv(pad, kx.view(1, 1, 3, 3))[0] / 32.0
+    gh = conv(pad, ky.view(1, 1, 3, 3))[0] / 32.0
+    full = conv((pad.abs() > eps).float(), torch.ones(1, 1, 3, 3, device=rgb.device))[0] == 9.0
+    mag = torch.sqrt((gv * full) ** 2 + (gh * full) ** 2)[0]
+    return mag > mag.median() * edge_threshold
+
+
 class Viewpoint:
     def __init__(self, idx, rgb, depth, device, gt_R=None, gt_T=None):
         self.frame_idx, self.device = idx, device
@@ -52,14 +68,7 @@ class Viewpoint:
         self.R_gt, self.T_gt = gt_R, gt_T
         self.rgb, self.depth = rgb, depth
         self.mask = torch.ones_like(depth, dtype=torch.bool)
-        # edge mask stand-in (the reference thresholds a Scharr gradient, utils/camera_utils.py:185-216)
-        gray = rgb.mean(0)
-        gx = torch.zeros_like(gray)
-        gy = torch.zeros_like(gray)
-        gx[:, 1:-1] = gray[:, 2:] - gray[:, :-2]
-        gy[1:-1] = gray[2:] - gray[:-2]
-        mag = torch.sqrt(gx * gx + gy * gy)
-        self.grad_mask = mag > mag.median() * 1.1
+        self.grad_mask = scharr_grad_mask(rgb)
         z = lambda n, v=0.0: torch.nn.Parameter(torch.full((n,), v, device=device))  # noqa: E731
         self.cam_rot_delta, self.cam_trans_delta = z(3), z(3)
         self.exposure_a, self.exposure_b = z(1), z(1)
@@ -106,7 +115,7 @@ class TrackingGraph:
     * The convergence flag is read back through a pinned buffer after every replay (or one replay late, `lookahead`).
     Result: identical poses and iteration counts to the eager loop with its per-iteration `if converged: break`."""
 
-    def __init__(self, proto: Viewpoint, intr, gmap, bg):
+    def __init__(self, proto: Viewpoint, intr, gmap, bg, exclusive: bool = True):
         from . import rasterizer as _r
         self._r = _r
         dev = proto.device
@@ -133,12 +142,14 @@ class TrackingGraph:
         torch.cuda.current_stream().wait_stream(s)
         self.opt.zero_grad()
         # two executable graphs of the same iteration, replayed alternately: launching a graph that is still running
-        # waits for it, a second instance lets replay n+1 queue behind replay n (the ~30 us launch gap disappears)
+        # waits for it, a second instance lets replay n+1 queue behind replay n (the ~30 us launch gap disappears).
+        # `exclusive`: this process owns the device and the replays run one after the other on one stream, so the small sorts
+        # may skip their ticket atomics (MGS_FLAG_EXCLUSIVE_DEVICE) -- NOT what a tracker beside a mapper process may assume.
         self.graphs = []
         for slot in range(2):
             self.opt.zero_grad()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g), _r.exclusive_device(exclusive):
                 self._iteration(host_flag=self.flags[slot])      # graph `slot` reports into its own pinned word
             self.graphs.append(g)
         self.graph = self.graphs[0]
@@ -232,10 +243,162 @@ def make_sequence(n_frames: int, intrinsics="fr3_office", n_gaussians=60000, see
     return frames, intr
 
 
+# ---- an OPAQUE-surface stand-in: a box room with furniture, ray-cast analytically -----------------------------------------
+# The cloud of `make_sequence` is semi-transparent by construction (its "depth" is a blend over several layers), so a map
+# fitted to it never gets past the reference's 0.7 opacity pruning threshold.  A real sequence shows opaque surfaces: this
+# one is a 6 x 3 x 6 m room with four boxes standing in it, every pixel's colour and z-depth computed in closed form
+# (ray / axis-aligned-box intersection, a procedural texture of the hit point), seen from a hand-held-like camera path.
+_ROOM_HALF = (3.0, 1.5, 3.0)
+_ROOM_BOXES = (   # (lo, hi) in world metres; y points down in the first camera, the floor is y = +1.5
+    ((-2.4, 0.55, 1.1), (-0.9, 1.5, 2.3)),      # a desk
+    ((0.9, -0.3, 1.8), (1.9, 1.5, 2.8)),        # a cabinet
+    ((-0.5, 0.9, 0.9), (0.4, 1.5, 1.6)),        # a crate in front
+    ((2.2, 0.2, -0.5), (3.0, 1.5, 0.9)),        # a shelf on the right wall
+)
+
+
+def _room_texture(p, axis, sid):
+    """Colour of the surface point ``p`` [N,3] whose normal is along ``axis`` [N]; ``sid`` [N] picks the base colour."""
+    dev = p.device
+    ia = torch.where(axis == 0, 1, 0)
+    ib = torch.where(axis == 2, 1, 2)
+    a = torch.gather(p, 1, ia[:, None])[:, 0]
+    b = torch.gather(p, 1, ib[:, None])[:, 0]
+    base = torch.tensor([[0.78, 0.72, 0.62], [0.55, 0.66, 0.80], [0.70, 0.80, 0.62], [0.82, 0.60, 0.58], [0.60, 0.60, 0.72],
+                         [0.85, 0.80, 0.55], [0.50, 0.72, 0.70], [0.75, 0.55, 0.75], [0.62, 0.78, 0.85], [0.80, 0.68, 0.50]],
+                        device=dev)[sid % 10]
+    two_pi = 2.0 * math.pi
+    ph = sid.to(torch.float32) * 1.7
+    slow = 0.5 + 0.5 * torch.sin(two_pi * 0.45 * a + ph) * torch.sin(two_pi * 0.38 * b + 0.6 * ph)
+    # a soft checker (edges 3 cm wide) and a fine weave: image gradients everywhere, as a textured office has
+    chk = torch.tanh(torch.sin(two_pi * a / 0.8) * torch.sin(two_pi * b / 0.8) * 12.0)
+    fine = torch.sin(two_pi * a / 0.11 + ph) * torch.sin(two_pi * b / 0.13)
+    lum = 0.62 + 0.16 * slow + 0.14 * chk + 0.06 * fine
+    tint = torch.stack([torch.sin(two_pi * 0.21 * a + ph), torch.sin(two_pi * 0.17 * b + 2.0 + ph),
+                        torch.sin(two_pi * 0.13 * (a + b) + 4.0)], 1) * 0.08
+    return (base * lum[:, None] + tint).clamp(0.02, 0.98)
+
+
+@torch.no_grad()
+def raycast_room(R, t, k, device):
+    """(rgb [3,H,W], depth [H,W]) of the room seen by the world->camera pose (R, t).  Pixel (x, y) looks along
+    ((x + 0.5 - cx) / fx, (y + 0.5 - cy) / fy, 1): the rasteriser's pixel convention (``px = fx X/Z + cx - 0.5``) and the
+    back-projection's (/root/reference/gaussian_splatting/scene/gaussian_model.py:232-236)."""
+    H, W = k["H"], k["W"]
+    ys, xs = torch.meshgrid(torch.arange(H, device=device, dtype=torch.float32),
+                            torch.arange(W, device=device, dtype=torch.float32), indexing="ij")
+    dc = torch.stack([(xs + 0.5 - k["cx"]) / k["fx"], (ys + 0.5 - k["cy"]) / k["fy"], torch.ones_like(xs)], -1).reshape(-1, 3)
+    R, t = R.to(device), t.to(device)
+    o = -(R.t() @ t)
+    d = dc @ R                                            # R^T d, row form
+    d = torch.where(d.abs() < 1e-9, torch.full_like(d, 1e-9), d)
+    half = torch.tensor(_ROOM_HALF, device=device)
+    t_wall = (torch.where(d > 0, half, -half) - o) / d    # the room from inside: the nearest exit plane
+    best, axis = t_wall.min(dim=1)
+    sid = axis * 2 + (torch.gather(d, 1, axis[:, None])[:, 0] > 0).long()
+    for bi, (lo, hi) in enumerate(_ROOM_BOXES):
+        lo, hi = torch.tensor(lo, device=device), torch.tensor(hi, device=device)
+        t1, t2 = (lo - o) / d, (hi - o) / d
+        tn, ax = torch.minimum(t1, t2).max(dim=1)
+        tf = torch.maximum(t1, t2).min(dim=1).values
+        hit = (tn < tf) & (tn > 1e-3) & (tn < best)
+        best = torch.where(hit, tn, best)
+        axis = torch.where(hit, ax, axis)
+        sid = torch.where(hit, 6 + bi * 3 + ax, sid)
+    p = o + best[:, None] * d
+    rgb = _room_texture(p, axis, sid)
+    return rgb.t().reshape(3, H, W).contiguous(), best.reshape(H, W).contiguous()
+
+
+def make_room_sequence(n_frames: int, intrinsics="fr3_office", device="cuda:0", step_scale: float = 1.0):
+    """``n_frames`` RGB-D frames of the room along a smooth hand-held-like path (about 1 cm and 0.3 degrees per frame at
+    ``step_scale`` 1: the inter-frame motion of a 30 Hz TUM sequence), ground-truth poses attached."""
+    k = dict(cam.INTRINSICS[intrinsics]) if isinstance(intrinsics, str) else dict(intrinsics)
+    intr = Intrinsics(k, device)
+    frames: List[Viewpoint] = []
+    for i in range(n_frames):
+        s = step_scale * i
+        c = torch.tensor([0.35 * math.sin(0.022 * s) - 0.2, 0.05 * math.sin(0.05 * s) + 0.1, -1.6 + 0.25 * (1 - math.cos(0.02 * s))])
+        yaw, pitch = 0.0055 * s - 0.1, 0.05 + 0.03 * math.sin(0.04 * s)
+        Rwc = cam.so3_exp(torch.tensor([0.0, yaw, 0.0])) @ cam.so3_exp(torch.tensor([pitch, 0.0, 0.0]))   # camera -> world
+        Rcw = Rwc.t().contiguous()
+        tcw = -(Rcw @ c)
+        rgb, depth = raycast_room(Rcw, tcw, k, device)
+        frames.append(Viewpoint(i, rgb, depth, device, gt_R=Rcw.to(device), gt_T=tcw.to(device)))
+    return frames, intr
+
+
+def reference_style_tracking_loss(render_image, render_depth, render_opacity, viewpoint):
+    """``get_loss_tracking`` in plain PyTorch ops, as the unmodified caller runs it (/root/reference/utils/slam_utils.py:58-98,
+    ``invert_depth=False``): what an eager loop that swaps ONLY the rasteriser pays between the forward and the backward."""
+    gt_depth = viewpoint.depth[None]
+    opacity_mask = render_opacity > 0.99
+    rgb = torch.exp(viewpoint.exposure_a) * render_image + viewpoint.exposure_b
+    rgb_mask = viewpoint.mask * viewpoint.grad_mask * opacity_mask
+    l1_rgb = (render_opacity * torch.abs(rgb * rgb_mask - viewpoint.rgb * rgb_mask).mean()).mean()
+    depth_mask = (gt_depth > 0) * opacity_mask
+    if depth_mask.any():
+        l1_depth = torch.abs(render_depth[depth_mask] - gt_depth[depth_mask]).mean()
+    else:
+        l1_depth = torch.zeros((), device=render_depth.device)
+    return 0.5 * l1_rgb + l1_depth
+
+
+def eager_tracking_probe(frames, intr, gmap, bg, iters: int):
+    """The rate an UNMODIFIED MonoGS tracker gets from the drop-in: the loop of /root/reference/utils/slam_tracker.py:138-176
+    -- ``render()`` through the seam (exact instance count: one read-back per forward, as upstream), the map's tensors
+    requiring grad as the tracker's copy of the Gaussians does, ``loss.backward()``, ``torch.optim.Adam`` on the four pose /
+    exposure parameters, ``update_pose`` -- with no hipGraph, no capacity mode, no fused pose step.  Two flavours:
+    ``torch_losses`` swaps only the rasteriser (the loss is the reference's ~60 torch kernels with their boolean-index
+    syncs), ``fused_losses`` also takes ``monogs_amd.fused_losses.get_loss_tracking`` (same signature).  Fixed iteration
+    count (no early exit), poses restored afterwards."""
+    from . import rasterizer as _r
+    was = _r.sync_free_enabled()
+    _r.set_sync_free(False)
+    vp = frames[-1]
+    keep = (vp.R.clone(), vp.T.clone(), vp.exposure_a.data.clone(), vp.exposure_b.data.clone())
+    out = {}
+    try:
+        for name, loss_fn in (("torch_losses", reference_style_tracking_loss), ("fused_losses", fused_losses.get_loss_tracking)):
+            opt = torch.optim.Adam([dict(params=[vp.cam_rot_delta], lr=0.003), dict(params=[vp.cam_trans_delta], lr=0.001),
+                                    dict(params=[vp.exposure_a], lr=0.01), dict(params=[vp.exposure_b], lr=0.01)])
+
+            def it():
+                opt.zero_grad()
+                pkg = render(vp, intr, gmap.get_xyz, gmap.get_rotation, gmap.get_scaling, gmap.get_opacity, gmap.get_features, bg)
+                loss = loss_fn(pkg["render"], pkg["depth"], pkg["opacity"], vp)
+                loss.backward()
+                with torch.no_grad():
+                    opt.step()
+                    vp.retract()
+            for _ in range(10):
+                it()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0 = time.perf_counter()
+            e0.record()
+            for _ in range(iters):
+                it()
+            e1.record()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            out[name] = dict(iters=iters, ms_per_iter=round(1e3 * dt / iters, 4), iters_per_s=round(iters / dt, 1))
+            with torch.no_grad():
+                vp.update_RT(keep[0].clone(), keep[1].clone())
+                vp.exposure_a.data.copy_(keep[2]); vp.exposure_b.data.copy_(keep[3])
+            for p in gmap.params():
+                p.grad = None
+    finally:
+        _r.set_sync_free(was)
+    out["gaussians"], out["width"], out["height"] = len(gmap), int(intr.width), int(intr.height)
+    return out
+
+
 def run_slam(n_frames=12, intrinsics="fr3_office", tracking_itr_num=100, mapping_itr_num=150, window_size=8,
              kf_interval=4, init_itr_num=300, n_gaussians=60000, device="cuda:0", log=None,
              init_downsample=8, kf_downsample=16, point_size=1.0, graph_tracking=False, graph_mapping=False,
-             track_lookahead=1, map_surgery=False, reference_lrs=False, prune_after_mapping=None):
+             track_lookahead=1, map_surgery=False, reference_lrs=False, prune_after_mapping=None,
+             scene="cloud", reference_densify=False, eager_probe=0):
     """Returns a dict with tracking / mapping FPS, iterations and the trajectory error.
 
     Mapping runs through ``monogs_amd.mapping.WindowMapper`` -- the SAME ``optimize_map`` / ``initialize_map`` the sharded
@@ -244,23 +407,39 @@ def run_slam(n_frames=12, intrinsics="fr3_office", tracking_itr_num=100, mapping
     learning-rate schedule, pose steps), replayed from hipGraphs when ``graph_mapping``.  Per keyframe, as ``Mapper.run``
     does (/root/reference/utils/slam_mapper.py:639-722): extend the map, fresh keyframe optimisers, ``optimize_map(iters)``,
     then ``optimize_map(prune=True, iters=1)`` (``prune_after_mapping``; default: with ``map_surgery``).
-    ``map_surgery``: densify_and_prune / opacity resets on the reference's schedule (off by default: the young synthetic maps
-    of the short test runs do not survive the reference's pruning thresholds).  ``reference_lrs``: the reference's learning
-    rates and xyz schedule (``gaussian_map.REFERENCE_LRS``) instead of the harness's historical ones."""
+    ``map_surgery``: densify_and_prune / opacity resets / covisibility pruning on the reference's schedule
+    (/root/reference/utils/slam_mapper.py:408-451,462-480).  ``reference_lrs``: the reference's learning rates and xyz schedule
+    (``gaussian_map.REFERENCE_LRS``) instead of the harness's historical ones.
+    ``scene``: "room" = opaque surfaces ray-cast analytically (``make_room_sequence``; survives the reference's 0.7 opacity
+    pruning), "cloud" = the semi-transparent random cloud of ``make_sequence`` (historical; does not).
+    ``reference_densify``: new Gaussians as the fork hard-codes them -- 1/32 of the pixels at initialisation, 1/64 per
+    keyframe, scale^2 = dist2 x min(0.05, 0.01 x median depth) (/root/reference/gaussian_splatting/scene/gaussian_model.py:166-178)
+    -- instead of ``init_downsample`` / ``kf_downsample`` / ``point_size``.
+    ``eager_probe`` > 0: after the run, that many tracking iterations of the UNMODIFIED caller loop
+    (/root/reference/utils/slam_tracker.py:138-176) against the final map, timed (``eager_tracking`` in the result)."""
     from .gaussian_map import REFERENCE_LRS, REFERENCE_LR_SCHEDULE
     from .mapping import WindowMapper
     if prune_after_mapping is None:
         prune_after_mapping = bool(map_surgery)
-    frames, intr = make_sequence(n_frames, intrinsics, n_gaussians, device=device)
+    if scene == "room":
+        frames, intr = make_room_sequence(n_frames, intrinsics, device=device)
+    else:
+        frames, intr = make_sequence(n_frames, intrinsics, n_gaussians, device=device)
+    if reference_densify:
+        extend_kw = lambda init: dict(downsample=32 if init else 64, point_size=None)  # noqa: E731
+    else:
+        extend_kw = lambda init: dict(downsample=init_downsample if init else kf_downsample, point_size=point_size)  # noqa: E731
     bg = torch.zeros(3, device=device)
     gmap = GaussianMap(device, **(dict(lrs=REFERENCE_LRS) if reference_lrs else {}))
     if reference_lrs:
         gmap.lr_schedule = dict(REFERENCE_LR_SCHEDULE)
+    gmap.surgery_log = []
     mapper = WindowMapper(gmap, intr, bg, window_size=window_size, use_graph=graph_mapping)
     mapper.map_surgery = bool(map_surgery)
     mapper.time_replays = True
     window: List[Viewpoint] = []
     per_frame, map_loss, window_sizes = [], [], []      # (frame, tracking iterations); (first, last) mapping loss per call
+    size_trace = []                                     # (frame, Gaussians in the map after that keyframe's mapping)
     stats = dict(kf_extend_s=0.0, track_capture_s=0.0, track_s=0.0, track_iters=0, tracked=0, map_s=0.0, map_iters=0,
                  keyframes=0, renders=0)
 
@@ -296,9 +475,10 @@ def run_slam(n_frames=12, intrinsics="fr3_office", tracking_itr_num=100, mapping
         if i == 0:
             vp.update_RT(vp.R_gt, vp.T_gt)
             sync(); t0 = time.perf_counter()
-            gmap.extend_from_frame(vp, intr, downsample=init_downsample, init=True, point_size=point_size)
+            gmap.extend_from_frame(vp, intr, init=True, **extend_kw(True))
             window.append(vp)
             map_window(init_itr_num, init=True)
+            size_trace.append((0, len(gmap)))
             sync(); stats["map_s"] += time.perf_counter() - t0
             stats["keyframes"] += 1
             continue
@@ -336,7 +516,7 @@ def run_slam(n_frames=12, intrinsics="fr3_office", tracking_itr_num=100, mapping
             with torch.no_grad():
                 pkg = _render(vp, intr, gmap, bg)
             sync(); te0 = time.perf_counter()
-            gmap.extend_from_frame(vp, intr, downsample=kf_downsample, render_opacity=pkg["opacity"], point_size=point_size)
+            gmap.extend_from_frame(vp, intr, render_opacity=pkg["opacity"], render_depth=pkg["depth"], **extend_kw(False))
             sync(); stats["kf_extend_s"] += time.perf_counter() - te0
             window.append(vp)
             if len(window) > window_size:
@@ -344,6 +524,7 @@ def run_slam(n_frames=12, intrinsics="fr3_office", tracking_itr_num=100, mapping
             map_window(mapping_itr_num)
             sync(); stats["map_s"] += time.perf_counter() - t0
             stats["keyframes"] += 1
+            size_trace.append((i, len(gmap)))
             if tgraph is not None:                   # the map changed: the captured tracking graph is stale
                 tgraph.close()
                 tgraph = None
@@ -359,6 +540,15 @@ def run_slam(n_frames=12, intrinsics="fr3_office", tracking_itr_num=100, mapping
     err = torch.stack([(-(f.R.t() @ f.T) + (f.R_gt.t() @ f.T_gt)).norm() for f in frames[1:]])
     ms = mapper.stats
     out = dict(stats)
+    sl = gmap.surgery_log
+    out["surgery"] = dict(
+        densify_and_prune_calls=len(sl), cloned=sum(e["cloned"] for e in sl), split_net=sum(e["split_net"] for e in sl),
+        pruned=sum(e["pruned"] for e in sl), calls_that_grew=sum(1 for e in sl if e["cloned"] + e["split_net"] > 0),
+        calls_that_pruned=sum(1 for e in sl if e["pruned"] > 0), covisibility_prunes=len(mapper.coviz_log),
+        covisibility_pruned=sum(n for _, n in mapper.coviz_log),
+        gaussians_after_keyframe=[n for _, n in size_trace], log=sl[:6] + sl[-4:] if len(sl) > 10 else sl)
+    if eager_probe:
+        out["eager_tracking"] = eager_tracking_probe(frames, intr, gmap, bg, int(eager_probe))
     out.update(frames=n_frames, gaussians=int(gmap.get_xyz.shape[0]), width=intr.width, height=intr.height,
                tracking_fps=stats["tracked"] / max(stats["track_s"], 1e-9),
                tracking_iters_per_s=stats["track_iters"] / max(stats["track_s"], 1e-9),
@@ -484,7 +674,18 @@ def run_slam_two_process(n_frames=12, intrinsics="fr3_office", tracking_itr_num=
         nonlocal snapshot, seq, tgraph
         t0 = time.perf_counter()
         q_in.put((tag, vp.frame_idx, vp.R.cpu().numpy(), vp.T.cpu().numpy()))
-        ans = q_out.get(timeout=600)
+        import queue as _queue
+        deadline = time.perf_counter() + 600.0
+        while True:                       # a dead mapper must not leave the tracker blocked for ten minutes
+            try:
+                ans = q_out.get(timeout=1.0)
+                break
+            except _queue.Empty:
+                if not proc.is_alive():
+                    raise RuntimeError(f"the mapper process died (exit code {proc.exitcode}) while the tracker waited for keyframe "
+                                       f"{vp.frame_idx}") from None
+                if time.perf_counter() > deadline:
+                    raise RuntimeError("the mapper process did not answer within 600 s") from None
         stats["wait_s"] += time.perf_counter() - t0
         _, idx, new_seq, P, t_map, t_pub, R, T, wlen = ans
         stats["map_s"] += t_map
@@ -510,7 +711,7 @@ def run_slam_two_process(n_frames=12, intrinsics="fr3_office", tracking_itr_num=
             vp.update_RT(prev.R.clone(), prev.T.clone())
             torch.cuda.synchronize(); t0 = time.perf_counter()
             if tgraph is None:
-                tgraph = TrackingGraph(vp, intr, snapshot, bg)
+                tgraph = TrackingGraph(vp, intr, snapshot, bg, exclusive=False)      # the mapper process shares the device
             n_it = tgraph.track(vp, tracking_itr_num)
             torch.cuda.synchronize(); stats["track_s"] += time.perf_counter() - t0
             assert not arena.stale(seq), "the mapper overwrote the snapshot the tracker was reading"
@@ -523,6 +724,12 @@ def run_slam_two_process(n_frames=12, intrinsics="fr3_office", tracking_itr_num=
             tgraph.close()
         q_in.put(("stop",))
         proc.join(timeout=120)
+        if proc.is_alive():               # hung: do not leave a child holding a HIP context and the IPC mappings behind
+            proc.terminate()
+            proc.join(timeout=10)
+            if proc.is_alive():
+                proc.kill()
+                proc.join(timeout=10)
         snapshot = None
         del arena
         import gc
@@ -531,6 +738,9 @@ def run_slam_two_process(n_frames=12, intrinsics="fr3_office", tracking_itr_num=
             torch.cuda.ipc_collect()
             time.sleep(0.05)
     wall = time.perf_counter() - t_all
+    exitcode = proc.exitcode
+    if exitcode != 0:
+        raise RuntimeError(f"the mapper process ended with exit code {exitcode}")
     err = torch.stack([(-(f.R.t() @ f.T) + (f.R_gt.t() @ f.T_gt)).norm() for f in frames[1:]])
     k = max(stats["keyframes"], 1)
     return dict(stats, frames=n_frames, wall_s=wall, fps_end_to_end=(n_frames - 1) / wall,
@@ -538,4 +748,4 @@ def run_slam_two_process(n_frames=12, intrinsics="fr3_office", tracking_itr_num=
                 tracking_fps=stats["tracked"] / max(stats["track_s"], 1e-9),
                 handoff_ms=dict(publish=1e3 * stats["publish_s"] / k, acquire=1e3 * stats["acquire_s"] / k),
                 mapper_busy_ms_per_keyframe=1e3 * stats["map_s"] / k, window_sizes=windows, gaussians=sizes, sequences=seqs,
-                ate_rmse_m=float(torch.sqrt((err ** 2).mean())), exitcode=proc.exitcode)
+                ate_rmse_m=float(torch.sqrt((err ** 2).mean())), exitcode=exitcode)

@@ -43,7 +43,7 @@ def test_scratch_size_functions_are_pure(native_lib):
 
 def test_struct_layout_matches_header():
     from monogs_amd import _lib
-    assert ctypes.sizeof(_lib.MgsCamera) == 8 * 4 + 5 * 8
+    assert ctypes.sizeof(_lib.MgsCamera) == 9 * 4 + 4 + 5 * 8       # nine 4-byte fields, padding, five pointers
     assert ctypes.sizeof(_lib.MgsTiming) == 9 * 4
 
 
@@ -66,3 +66,29 @@ def test_product_path_has_no_cpu_fallback():
     from monogs_amd.knn import distCUDA2
     with pytest.raises(RuntimeError, match="no CPU path"):
         distCUDA2(torch.zeros(10, 3))
+
+
+def test_maps_beyond_the_gradient_line_offset_are_refused(native_lib):
+    """The blend backward addresses a gradient line as index * 64 + slot in 32 bits (csrc/blend.hip, bt_flush): P >= 2^26 must
+    come back as an argument error from every entry point that takes a map, before anything is launched (no GPU needed)."""
+    from monogs_amd import _lib
+    text = open(os.path.join(ROOT, "include", "monogs_raster.h")).read()
+    assert re.search(r"#define MGS_MAX_GAUSSIANS \(\(1 << 26\) - 1\)", text)
+    cam = _lib.MgsCamera()
+    cam.image_height, cam.image_width = 16, 16
+    for f in ("bg", "viewmatrix", "projmatrix", "projmatrix_raw", "campos"):
+        setattr(cam, f, 0x1000)                      # non-NULL and never dereferenced: the size check comes first
+    for name in ("mgs_forward_preprocess", "mgs_forward_capacity", "mgs_forward_render", "mgs_forward_render_capacity",
+                 "mgs_backward"):
+        args = []
+        for k, t in enumerate(_lib.SIGNATURES[name][1]):
+            if k == 0:
+                args.append(ctypes.byref(cam))
+            elif k == 1:
+                args.append(1 << 26)                 # P
+            elif t in (ctypes.c_uint64, ctypes.c_int32):
+                args.append(1)
+            else:
+                args.append(None)
+        assert getattr(native_lib, name)(*args) == 1, name
+        assert b"MGS_MAX_GAUSSIANS" in native_lib.mgs_last_error(), (name, native_lib.mgs_last_error())

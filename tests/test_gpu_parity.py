@@ -136,6 +136,115 @@ def test_c2_100k(native_lib):
     print({k: (f"{a:.2e}", f"{b:.1e}") for k, (a, b) in rep.items()})
 
 
+def _c2_frame(color, depth, seed=1):
+    """A seeded synthetic RGB-D "ground-truth" frame for BASELINE config 2 (upstream gradients come from
+    ``get_loss_mapping``, /root/reference/utils/slam_utils.py:101-146): the rendered frame disturbed by smooth colour noise and
+    5 % depth noise, with what a sensor frame has and a uniform random gradient lacks -- a masked-out image border and masked
+    patches (``viewpoint.mask``: no colour gradient there), depth holes (``depth == 0``: no depth gradient there)."""
+    import types
+    g = torch.Generator().manual_seed(seed)
+    H, W = depth.shape[-2:]
+    low = torch.rand(1, 3, H // 16 + 1, W // 16 + 1, generator=g)
+    noise = torch.nn.functional.interpolate(low, size=(H, W), mode="bilinear", align_corners=False)[0] - 0.5
+    rgb = (color + 0.3 * noise).clamp(0, 1)
+    d = depth[0] * (1 + 0.05 * torch.randn(H, W, generator=g))
+    holes = torch.nn.functional.interpolate(torch.rand(1, 1, H // 8 + 1, W // 8 + 1, generator=g), size=(H, W))[0, 0] < 0.12
+    d = torch.where(holes | (depth[0] <= 0), torch.zeros_like(d), d)
+    mask = torch.ones(H, W, dtype=torch.bool)
+    mask[:12], mask[-12:], mask[:, :12], mask[:, -12:] = False, False, False, False
+    mask &= torch.nn.functional.interpolate(torch.rand(1, 1, H // 32 + 1, W // 32 + 1, generator=g), size=(H, W))[0, 0] > 0.1
+    return types.SimpleNamespace(rgb=rgb, depth=d, mask=mask, exposure_a=torch.tensor([0.03]), exposure_b=torch.tensor([-0.02]))
+
+
+def test_c2_100k_mapping_loss_gradients(native_lib):
+    """BASELINE config 2 as SURVEY.md section 8d defines it: 100 k Gaussians, 640x480, "RGB-D single frame" = the upstream
+    gradients are those of ``get_loss_mapping`` against a seeded synthetic RGB-D frame -- piecewise-constant +-lambda / N on
+    the valid pixels, exactly ZERO on masked-out pixels and in depth holes -- not uniform noise.  The HIP side runs the whole
+    chain (rasteriser forward -> fused loss -> loss.backward() -> rasteriser backward); the oracle takes the SAME upstream
+    tensors (from the PyTorch loss mirror, which tests/test_golden.py pins to the reference's own outputs, evaluated on the
+    HIP images) through its own autograd."""
+    import types
+    from monogs_amd import fused_losses
+    from monogs_amd.rasterizer import GaussianRasterizer
+    from oracle.slam_losses import get_loss_mapping as loss_ref
+    sc = make_scene(100000, "fr3_office", seed=1)
+    inp = _inputs(sc)
+    st = _hip_settings(sc)
+    leaves = {k: v.to(DEV).clone().requires_grad_(True) for k, v in inp.items()}
+    means2D = torch.zeros_like(leaves["means3D"], requires_grad=True)
+    theta = torch.zeros(3, device=DEV, requires_grad=True)
+    rho = torch.zeros(3, device=DEV, requires_grad=True)
+    color, radii, depth, opacity, n_touched = GaussianRasterizer(st)(
+        means3D=leaves["means3D"], means2D=means2D, opacities=leaves["opacities"], colors_precomp=leaves["colors_precomp"],
+        scales=leaves["scales"], rotations=leaves["rotations"], theta=theta, rho=rho)
+    vp_cpu = _c2_frame(color.detach().cpu(), depth.detach().cpu())
+    vp = types.SimpleNamespace(rgb=vp_cpu.rgb.to(DEV), depth=vp_cpu.depth.to(DEV), mask=vp_cpu.mask.to(DEV),
+                               exposure_a=vp_cpu.exposure_a.to(DEV).requires_grad_(True),
+                               exposure_b=vp_cpu.exposure_b.to(DEV).requires_grad_(True))
+    loss = fused_losses.get_loss_mapping(color, depth, vp)
+    loss.backward()
+    grads = {k: v.grad.cpu() for k, v in leaves.items()}
+    grads.update(means2D=means2D.grad.cpu(), theta=theta.grad.cpu(), rho=rho.grad.cpu())
+    # the same loss in plain PyTorch on the HIP images: value, upstream gradients, exposure gradients
+    c_ref, d_ref = color.detach().cpu().requires_grad_(True), depth.detach().cpu().requires_grad_(True)
+    vp_cpu.exposure_a.requires_grad_(True); vp_cpu.exposure_b.requires_grad_(True)
+    l_ref = loss_ref(c_ref, d_ref, vp_cpu)
+    g_color, g_depth, g_a, g_b = torch.autograd.grad(l_ref, [c_ref, d_ref, vp_cpu.exposure_a, vp_cpu.exposure_b])
+    assert abs(float(loss) - float(l_ref)) <= 1e-5 * abs(float(l_ref))
+    assert torch.allclose(vp.exposure_a.grad.cpu(), g_a, rtol=1e-3, atol=1e-7) and torch.allclose(vp.exposure_b.grad.cpu(), g_b, rtol=1e-3, atol=1e-7)
+    # the upstream gradient has what C2 is about: zero regions and a piecewise-constant magnitude
+    zero_c, zero_d = (g_color.abs().sum(0) == 0).float().mean().item(), (g_depth[0] == 0).float().mean().item()
+    print(f"C2 (mapping loss): dL/dcolor zero on {zero_c:.1%} of the pixels, dL/ddepth zero on {zero_d:.1%}")
+    assert 0.05 < zero_c < 0.6 and 0.05 < zero_d < 0.8
+    oout, ograds = rasterize_autograd(inp, scene_settings(sc, OracleSettings), g_color, g_depth, dtype=torch.float32,
+                                      want_ambiguous=True)
+    ok = ~oout.aux["ambiguous"]
+    assert (color.detach().cpu() - oout.color).abs().amax(0)[ok].max() <= 1e-4
+    rep = _check_grads(grads, ograds)
+    print({k: (f"{a:.2e}", f"{b:.1e}") for k, (a, b) in rep.items()})
+
+
+@pytest.mark.parametrize("pose_only", [False, True])
+@pytest.mark.parametrize("P,intr,seed", [(5000, "fr3_office", 0), (100000, "fr3_office", 1), (60000, "replica", 4)])
+def test_blend_backward_paths_agree(native_lib, P, intr, seed, pose_only):
+    """The two blend backwards -- `blend_backward_t_kernel` (default: per-pixel factors through LDS, one row reduction per
+    four survivors) and `blend_backward_kernel` (its A/B partner behind mgs_debug_set_option("blend_bwd_transposed", 0): one
+    64-lane reduction per survivor) -- form the same sums in a different order: every gradient agrees to 1e-6 relative L2,
+    in the ten-sum and in the six-sum (pose-only: the map takes no gradient) variant."""
+    from monogs_amd.rasterizer import GaussianRasterizer
+    sc = make_scene(P, intr, seed=seed)
+    st = _hip_settings(sc)
+    inp = {k: v.to(DEV) for k, v in _inputs(sc).items()}
+    gc, gd = sc.grad_color.to(DEV), sc.grad_depth.to(DEV)
+
+    def run():
+        leaves = {k: (v.clone() if pose_only else v.clone().requires_grad_(True)) for k, v in inp.items()}
+        theta = torch.zeros(3, device=DEV, requires_grad=True)
+        rho = torch.zeros(3, device=DEV, requires_grad=True)
+        m2 = torch.zeros_like(leaves["means3D"], requires_grad=not pose_only)
+        out = GaussianRasterizer(st)(means3D=leaves["means3D"], means2D=m2, opacities=leaves["opacities"],
+                                     colors_precomp=leaves["colors_precomp"], scales=leaves["scales"],
+                                     rotations=leaves["rotations"], theta=theta, rho=rho)
+        torch.autograd.backward([out[0], out[2]], [gc, gd])
+        g = dict(theta=theta.grad.clone(), rho=rho.grad.clone())
+        if not pose_only:
+            g.update({k: v.grad.clone() for k, v in leaves.items()}, means2D=m2.grad.clone())
+        return g
+    try:
+        native_lib.mgs_debug_set_option(b"blend_bwd_transposed", 1)
+        a = run()
+        native_lib.mgs_debug_set_option(b"blend_bwd_transposed", 0)
+        b = run()
+    finally:
+        native_lib.mgs_debug_set_option(b"blend_bwd_transposed", 1)
+    assert set(a) == set(b) and len(a) == (2 if pose_only else 8)
+    for k in a:
+        x, y = a[k].double(), b[k].double()
+        assert y.norm() > 0, k
+        rel = ((x - y).norm() / y.norm()).item()
+        assert rel <= (1e-5 if k in ("theta", "rho") else 1e-6), (k, rel)      # (6 floats summed over the whole map)
+
+
 def test_knn(native_lib):
     from monogs_amd.knn import distCUDA2
     from oracle import dist2_knn

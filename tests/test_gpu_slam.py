@@ -32,16 +32,18 @@ def test_tracking_converges_and_reduces_the_pose_error(runs):
 
 def test_graph_tracking_equals_eager_tracking(native_lib):
     """A captured tracking iteration replayed until the device-side convergence flag rises = the eager loop with its
-    per-iteration `if converged: break` (/root/reference/utils/slam_tracker.py:138-188).  Same map, same frame, same
-    start pose for both, so the only difference left is summation order (float atomics; the eager loop runs the ten-sum
-    backward, the graph the six-sum pose-only one): poses agree to 1e-5.  The iteration counts agree to within a tenth:
-    near the end the Adam step hovers around the 1e-4 exit threshold for several iterations (69 vs 65 was observed), so
-    WHICH of them first dips below it is decided by the last bits of the gradient."""
-    import copy
+    per-iteration `if converged: break` (/root/reference/utils/slam_tracker.py:138-188).  Like with like: same map, same
+    frame, same start pose, and BOTH loops render the frozen map (no gradient for the Gaussians), so both run the six-sum
+    pose-only blend backward and the only difference left is the order of its float atomics.  Poses agree to 1e-5.  The
+    iteration COUNT is not compared: near the end the Adam step hovers around the 1e-4 exit threshold for several
+    iterations and the last bits of the gradient decide which of them dips below it first (69 vs 65 was observed) -- instead
+    the convergence logic is checked exactly: the flag is up, and the device-side Adam step count equals the iterations the
+    graph loop reports (a surplus replay after convergence is a no-op: the flag is sticky)."""
     from monogs_amd import fused_losses
     from monogs_amd.gaussian_map import GaussianMap
-    from monogs_amd.mapping import WindowMapper, render_map
+    from monogs_amd.mapping import WindowMapper
     from monogs_amd.pose_optim import PoseAdam
+    from monogs_amd.renderer import render
     from monogs_amd.slam_harness import TrackingGraph, Viewpoint, make_sequence
     dev = "cuda:0"
     frames, intr = make_sequence(3, "fr3_office", n_gaussians=30000, device=dev)
@@ -52,6 +54,9 @@ def test_graph_tracking_equals_eager_tracking(native_lib):
     mapper = WindowMapper(gmap, intr, bg, window_size=8)
     mapper.map_surgery = False                      # (the mapping thresholds would prune this 80-iteration-old map)
     mapper.optimize_map([frames[0]], iters=80, init=True)                                            # one map for both loops
+    with torch.no_grad():
+        frozen = (gmap.get_xyz.detach(), gmap.get_rotation.detach(), gmap.get_scaling.detach(), gmap.get_opacity.detach(),
+                  gmap.get_features.detach())
 
     def start(i):                     # frame i, starting from the previous frame's true pose (as the tracker does)
         f = frames[i]
@@ -65,21 +70,21 @@ def test_graph_tracking_equals_eager_tracking(native_lib):
         opt = PoseAdam(ve, 0.003, 0.001, 0.01)
         n_eager = 100
         for it in range(100):
-            pkg = render_map(ve, intr, gmap, bg)
+            pkg = render(ve, intr, *frozen, bg)
             opt.zero_grad()
             fused_losses.get_loss_tracking(pkg["render"], pkg["depth"], pkg["opacity"], ve).backward()
             with torch.no_grad():
                 if opt.step_and_retract():
                     n_eager = it + 1
                     break
-        for p in gmap.params():
-            p.grad = None
         # ---- hipGraph: the same iteration captured once, replayed until the sticky device flag rises
         vg = start(i)
         tg = TrackingGraph(vg, intr, gmap, bg)
         n_graph = tg.track(vg, 100)
+        flag_up, steps = float(tg.opt.out[0]) > 0.5, int(tg.opt.t_dev.item())
         tg.close()
-        assert 1 < n_eager < 100 and abs(n_eager - n_graph) <= max(3, n_eager // 10), (i, n_eager, n_graph)
+        assert 1 < n_eager < 100 and 1 < n_graph < 100, (i, n_eager, n_graph)
+        assert flag_up and steps == n_graph, (i, flag_up, steps, n_graph)
         assert (ve.R - vg.R).abs().max() < 1e-5 and (ve.T - vg.T).abs().max() < 1e-5, (i, (ve.R - vg.R).abs().max())
         err0 = (-(frames[i - 1].R_gt.t() @ frames[i - 1].T_gt) + (frames[i].R_gt.t() @ frames[i].T_gt)).norm()
         err1 = (-(vg.R.t() @ vg.T) + (frames[i].R_gt.t() @ frames[i].T_gt)).norm()

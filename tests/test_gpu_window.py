@@ -321,6 +321,34 @@ def test_pruning_call_gradients_are_carried_once(native_lib, tmp_path):
             assert (a.double() - c.double()).norm() <= 2e-4 * c.double().norm() + 1e-7, (k, _rel(a, c))
 
 
+@pytest.mark.gpu
+def test_full_window_pruning_call_keeps_pose_gradients(native_lib):
+    """slam_mapper.py:408-451 returns right after prune_points: the Gaussian gradients go with the replaced tensors, the pose /
+    exposure gradients of the pruning iteration STAY in .grad (nothing zeroes them) and join the first step of the next call."""
+    from monogs_amd.mapping import WindowMapper
+    dev = "cuda:0"
+    frames, intr, gmap = _c4_setup(dev, 3, "fr3_office", 20000, 8)
+    mapper = WindowMapper(gmap, intr, torch.zeros(3, device=dev), window_size=3)        # window of 3 == 3: full
+    mapper.map_surgery = False
+    mapper.prune_coviz = 1
+    mapper.optimize_map(frames, iters=2)
+    for vp in frames:
+        assert vp.cam_rot_delta.grad is None and vp.exposure_a.grad is None             # zeroed after a normal iteration
+    mapper.optimize_map(frames, prune=True, iters=1)
+    moved = [vp for vp in frames if vp.frame_idx != 0]
+    for vp in moved:
+        for q in (vp.cam_rot_delta, vp.cam_trans_delta, vp.exposure_a, vp.exposure_b):
+            assert q.grad is not None and bool(torch.isfinite(q.grad).all())
+        assert float(vp.cam_rot_delta.grad.abs().sum()) > 0
+    assert all(q.grad is None for q in gmap.params())
+    kept = [vp.cam_trans_delta.grad.clone() for vp in moved]
+    mapper.keep_reduced_grads = True
+    mapper.optimize_map(frames, iters=1)               # takes them in (eager first iteration), steps, zeroes
+    for vp in moved:
+        assert vp.cam_trans_delta.grad is None
+    assert all(bool(torch.isfinite(k).all()) for k in kept)
+
+
 def _run_rccl_one_rank(rank, world, port, out):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist

@@ -348,29 +348,53 @@ def eager_tracking_probe(frames, intr, gmap, bg, iters: int):
     """The rate an UNMODIFIED MonoGS tracker gets from the drop-in: the loop of /root/reference/utils/slam_tracker.py:138-176
     -- ``render()`` through the seam (exact instance count: one read-back per forward, as upstream), the map's tensors
     requiring grad as the tracker's copy of the Gaussians does, ``loss.backward()``, ``torch.optim.Adam`` on the four pose /
-    exposure parameters, ``update_pose`` -- with no hipGraph, no capacity mode, no fused pose step.  Two flavours:
-    ``torch_losses`` swaps only the rasteriser (the loss is the reference's ~60 torch kernels with their boolean-index
-    syncs), ``fused_losses`` also takes ``monogs_amd.fused_losses.get_loss_tracking`` (same signature).  Fixed iteration
-    count (no early exit), poses restored afterwards."""
+    exposure parameters, ``update_pose`` -- with no hipGraph, no capacity mode.  Flavours, each a superset of the one before:
+    ``torch_losses``      swaps ONLY the rasteriser: the loss is the reference's own torch ops (with their boolean-index
+                          syncs), the pose step ``torch.optim.Adam`` + ``update_pose`` in torch ops (a host read-back each);
+    ``fused_losses``      + ``monogs_amd.fused_losses.get_loss_tracking`` (same signature, two launches);
+    ``fused_pose_step``   + ``PoseAdam.step_and_retract`` (Adam + retraction + camera tensors in one launch);
+    ``render_loss_backward`` the part this repository owns, alone: render + fused loss + backward, no pose step (what
+                          tools/host_overhead.py times), with the device span of the same iterations beside it.
+    Fixed iteration count (no early exit), pose and exposure restored afterwards."""
     from . import rasterizer as _r
     was = _r.sync_free_enabled()
     _r.set_sync_free(False)
     vp = frames[-1]
     keep = (vp.R.clone(), vp.T.clone(), vp.exposure_a.data.clone(), vp.exposure_b.data.clone())
     out = {}
+
+    def map_tensors():
+        return (gmap.get_xyz, gmap.get_rotation, gmap.get_scaling, gmap.get_opacity, gmap.get_features)
+
+    def restore():
+        with torch.no_grad():
+            vp.update_RT(keep[0].clone(), keep[1].clone())
+            vp.exposure_a.data.copy_(keep[2]); vp.exposure_b.data.copy_(keep[3])
+            vp.cam_rot_delta.data.zero_(); vp.cam_trans_delta.data.zero_()
+        for p in gmap.params():
+            p.grad = None
     try:
-        for name, loss_fn in (("torch_losses", reference_style_tracking_loss), ("fused_losses", fused_losses.get_loss_tracking)):
-            opt = torch.optim.Adam([dict(params=[vp.cam_rot_delta], lr=0.003), dict(params=[vp.cam_trans_delta], lr=0.001),
-                                    dict(params=[vp.exposure_a], lr=0.01), dict(params=[vp.exposure_b], lr=0.01)])
+        for name in ("torch_losses", "fused_losses", "fused_pose_step", "render_loss_backward"):
+            loss_fn = reference_style_tracking_loss if name == "torch_losses" else fused_losses.get_loss_tracking
+            if name in ("torch_losses", "fused_losses"):
+                opt = torch.optim.Adam([dict(params=[vp.cam_rot_delta], lr=0.003), dict(params=[vp.cam_trans_delta], lr=0.001),
+                                        dict(params=[vp.exposure_a], lr=0.01), dict(params=[vp.exposure_b], lr=0.01)])
+                zero = opt.zero_grad
+            else:
+                popt = PoseAdam(vp, 0.003, 0.001, 0.01)
+                zero = popt.zero_grad
 
             def it():
-                opt.zero_grad()
-                pkg = render(vp, intr, gmap.get_xyz, gmap.get_rotation, gmap.get_scaling, gmap.get_opacity, gmap.get_features, bg)
+                zero()
+                pkg = render(vp, intr, *map_tensors(), bg)
                 loss = loss_fn(pkg["render"], pkg["depth"], pkg["opacity"], vp)
                 loss.backward()
                 with torch.no_grad():
-                    opt.step()
-                    vp.retract()
+                    if name in ("torch_losses", "fused_losses"):
+                        opt.step()
+                        vp.retract()
+                    elif name == "fused_pose_step":
+                        popt.step_and_retract()
             for _ in range(10):
                 it()
             torch.cuda.synchronize()
@@ -383,14 +407,32 @@ def eager_tracking_probe(frames, intr, gmap, bg, iters: int):
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
             out[name] = dict(iters=iters, ms_per_iter=round(1e3 * dt / iters, 4), iters_per_s=round(iters / dt, 1))
-            with torch.no_grad():
-                vp.update_RT(keep[0].clone(), keep[1].clone())
-                vp.exposure_a.data.copy_(keep[2]); vp.exposure_b.data.copy_(keep[3])
-            for p in gmap.params():
-                p.grad = None
+            restore()
+        # device time of render + loss + backward alone: the same iteration with the host queued ahead (capacity mode)
+        _r.set_sync_free(True)
+        popt = PoseAdam(vp, 0.003, 0.001, 0.01)
+
+        def it_dev():
+            popt.zero_grad()
+            pkg = render(vp, intr, *map_tensors(), bg)
+            fused_losses.get_loss_tracking(pkg["render"], pkg["depth"], pkg["opacity"], vp).backward()
+        for _ in range(10):
+            it_dev()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            it_dev()
+        e1.record()
+        torch.cuda.synchronize()
+        out["render_loss_backward"]["device_ms_per_iter"] = round(e0.elapsed_time(e1) / iters, 4)
+        _r.check_overflow()
+        restore()
     finally:
         _r.set_sync_free(was)
     out["gaussians"], out["width"], out["height"] = len(gmap), int(intr.width), int(intr.height)
+    out["note"] = ("eager, exact instance count (one read-back per forward), map tensors require grad (ten-sum backward), fixed "
+                   "iteration count against the final map of the run")
     return out
 
 

@@ -191,7 +191,8 @@ def test_c2_100k_mapping_loss_gradients(native_lib):
     l_ref = loss_ref(c_ref, d_ref, vp_cpu)
     g_color, g_depth, g_a, g_b = torch.autograd.grad(l_ref, [c_ref, d_ref, vp_cpu.exposure_a, vp_cpu.exposure_b])
     assert abs(float(loss) - float(l_ref)) <= 1e-5 * abs(float(l_ref))
-    assert torch.allclose(vp.exposure_a.grad.cpu(), g_a, rtol=1e-3, atol=1e-7) and torch.allclose(vp.exposure_b.grad.cpu(), g_b, rtol=1e-3, atol=1e-7)
+    # (sums of ~10^6 signed terms of magnitude 1 / N that cancel to ~3e-4: compared on the scale of the terms, not of the sum)
+    assert torch.allclose(vp.exposure_a.grad.cpu(), g_a, rtol=1e-3, atol=3e-6) and torch.allclose(vp.exposure_b.grad.cpu(), g_b, rtol=1e-3, atol=3e-6)
     # the upstream gradient has what C2 is about: zero regions and a piecewise-constant magnitude
     zero_c, zero_d = (g_color.abs().sum(0) == 0).float().mean().item(), (g_depth[0] == 0).float().mean().item()
     print(f"C2 (mapping loss): dL/dcolor zero on {zero_c:.1%} of the pixels, dL/ddepth zero on {zero_d:.1%}")

@@ -124,3 +124,31 @@ def test_two_process_run_hands_the_map_over_through_the_arena(native_lib):
     assert r["gaussians"][0] > 1000 and all(b >= a for a, b in zip(r["gaussians"], r["gaussians"][1:]))   # the map only grows
     assert r["tracked"] == 6 and r["ate_rmse_m"] < 3e-3, r["ate_rmse_m"]
     assert r["handoff_ms"]["publish"] < 50 and r["handoff_ms"]["acquire"] < 5, r["handoff_ms"]
+
+
+def test_tracking_and_mapping_with_the_reference_map_surgery(native_lib):
+    """BASELINE config 3 with EVERYTHING optimize_map does (/root/reference/utils/slam_mapper.py:408-451,462-480): densify_and_prune
+    every 150 iterations at the 0.7 opacity threshold, covisibility pruning after each keyframe once the window is full,
+    the fork's new-Gaussian recipe (1/32 and 1/64 of the pixels, scale^2 = dist2 x min(0.05, 0.01 x median depth)) and its
+    learning rates -- on a sequence of OPAQUE surfaces (a ray-cast room), hipGraph-replayed with a re-capture after every
+    map-size change.  The map must neither collapse nor explode, both halves of the surgery must fire, and tracking must
+    keep converging against the maps the surgery leaves behind."""
+    from monogs_amd.slam_harness import run_slam
+    r = run_slam(n_frames=13, intrinsics="fr3_office", tracking_itr_num=100, mapping_itr_num=150, window_size=5, kf_interval=2,
+                 init_itr_num=1050, scene="room", reference_densify=True, map_surgery=True, reference_lrs=True,
+                 graph_tracking=True, graph_mapping=True)
+    s = r["surgery"]
+    sizes = s["gaussians_after_keyframe"]
+    print("map size after each keyframe:", sizes, {k: v for k, v in s.items() if k not in ("log", "gaussians_after_keyframe")})
+    assert r["map_surgery"] and len(sizes) == 7 and r["window_sizes"][-1] == 5
+    assert s["densify_and_prune_calls"] >= 14                      # 11 of initialize_map + one per 150 mapping iterations
+    assert s["cloned"] + s["split_net"] > 5000 and s["calls_that_grew"] >= 10        # densification fires ...
+    assert s["pruned"] > 1000 and s["calls_that_pruned"] >= 1                         # ... and so does the opacity prune
+    assert s["covisibility_prunes"] >= 2                           # the window of five is full from the fifth keyframe on
+    assert min(sizes) > 4000 and max(sizes) < 150000, sizes        # 9 600 initial Gaussians: no collapse, no explosion
+    assert r["mapping_captures"] >= 6 and r["mapping_replays"] > 1500
+    # tracking after surgery: every frame converges before the iteration cap and lands within a centimetre
+    assert all(1 < n < 100 for _, n in r["track_iters_per_frame"]), r["track_iters_per_frame"]
+    assert max(r["position_error_m"]) < 1e-2 and r["ate_rmse_m"] < 5e-3, (r["ate_rmse_m"], r["position_error_m"])
+    first, last = r["map_loss"][0]
+    assert last < 0.1 * first                                      # map initialisation from sparse dots to a covered image

@@ -32,6 +32,10 @@ if __name__ == "__main__":
     ap.add_argument("--eager-mapping", action="store_true", help="with --graph: capture tracking only")
     ap.add_argument("--surgery", action="store_true", help="densify_and_prune / opacity resets / covisibility pruning on the reference's schedule")
     ap.add_argument("--reference-lrs", action="store_true", help="the reference's learning rates + xyz schedule")
+    ap.add_argument("--room", action="store_true", help="opaque box-room sequence (ray-cast) instead of the semi-transparent cloud")
+    ap.add_argument("--reference-densify", action="store_true",
+                    help="new Gaussians as the fork hard-codes them: 1/32 (init) and 1/64 of the pixels, scale^2 = dist2 x min(0.05, 0.01 x median depth)")
+    ap.add_argument("--eager-probe", type=int, default=0, help="after the run: N iterations of the unmodified eager tracking loop, timed")
     ap.add_argument("--fork", action="store_true",
                     help="the values the fork hard-codes over its YAML (/root/reference/utils/slam_tracker.py:70-72, "
                          "utils/slam_mapper.py:64-89,660-662, slam.py:75): tracking 100, every frame a keyframe, init 1050, "
@@ -51,7 +55,8 @@ if __name__ == "__main__":
             cfg[k] = v
     out = run_slam(n_frames=a.frames, init_itr_num=init_iters, n_gaussians=a.gaussians, graph_tracking=a.graph,
                    graph_mapping=a.graph and not a.eager_mapping, track_lookahead=a.lookahead, map_surgery=a.surgery,
-                   reference_lrs=a.reference_lrs, log=lambda s: print("[slam]", s, file=sys.stderr, flush=True), **cfg)
+                   reference_lrs=a.reference_lrs, scene="room" if a.room else "cloud", reference_densify=a.reference_densify,
+                   eager_probe=a.eager_probe, log=lambda s: print("[slam]", s, file=sys.stderr, flush=True), **cfg)
     out["workload"] = f"synthetic {a.config}-like sequence, {a.frames} frames" + (" (fork's hard-coded run configuration)" if a.fork else "")
     for k in ("poses", "camera_centers", "camera_centers_gt"):      # tensors: not JSON
         out.pop(k, None)

@@ -190,10 +190,12 @@ def bench_c4(args, rank, world, dev, distributed, rehearsal):
     mapper.optimize_map(frames, iters=n_prof)
     comm_ms = mapper.exposed_comm_s / n_prof * 1e3
     mapper.sync_poses(frames)
-    in_sync = True
+    in_sync, comm = True, None
     if distributed:
         from monogs_amd.window import replicas_in_sync
         in_sync = replicas_in_sync(gmap.params())
+        comm = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "devices_visible": torch.cuda.device_count(),
+                "device": torch.cuda.get_device_name(dev)}
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
@@ -213,9 +215,12 @@ def bench_c4(args, rank, world, dev, distributed, rehearsal):
             "mapping_iters_per_s": round(args.steps / dt, 2), "exchange_exposed_ms": round(comm_ms, 4),
             "exchange_bytes": {"allreduce_sum": 4 * P * 16, "allgather_per_rank": 8 * ((P + 1) // 2 + ((args.window + world - 1) // world) * ((P + 63) // 64))},
             "replicas_in_sync": bool(in_sync), "mapper_stats": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in mapper.stats.items()},
-            "roofline": None, "cpu_baseline": None,
+            "roofline": None, "cpu_baseline": None, "comm": comm,
         }
         print(json.dumps(line), flush=True)
+    if not in_sync:
+        print(f"[bench] rank {rank}: the replicated maps DIVERGED across the ranks", file=sys.stderr, flush=True)
+        raise SystemExit(3)
 
 
 def main():
@@ -334,10 +339,36 @@ def main():
             step(stats="time_exchange")
         torch.cuda.synchronize()
         ms = sorted(a.elapsed_time(b) for a, b in state["exchange_events"])
-        exchange = {"bytes": int(sum(p.numel() for p in params) * 4),
-                    "allreduce_ms": round(ms[len(ms) // 2], 4),
-                    "note": "median of 5 un-timed steps, HIP events around the collective on the launch stream; ms_per_step "
-                            "contains it in full (the gradients are complete only when the backward ends)"}
+        nbytes = int(sum(p.numel() for p in params) * 4)
+        t_ex = ms[len(ms) // 2] * 1e-3
+        exchange = {"bytes": nbytes, "allreduce_ms": round(ms[len(ms) // 2], 4),
+                    "allreduce_ms_min_max": [round(ms[0], 4), round(ms[-1], 4)],
+                    # nccl-tests convention: algorithm bandwidth = bytes / time, bus bandwidth = x 2 (N - 1) / N (what each link
+                    # of a ring carries); xGMI: 7 links x ~153 GB/s per GPU
+                    "algbw_gbs": round(nbytes / t_ex / 1e9, 2), "busbw_gbs": round(nbytes / t_ex / 1e9 * 2 * (world - 1) / world, 2),
+                    "collectives_per_step": bucket.last_collectives,
+                    "note": "median of 5 un-timed steps, HIP events around pack + collective + unpack on the launch stream; "
+                            "ms_per_step contains it in full (the gradients are complete only when the backward ends)"}
+        # every rank must hold the same reduced gradients, bit for bit (what keeps the replicated maps identical with no
+        # parameter broadcast): a 64-bit checksum per tensor, MIN / MAX over the ranks
+        from monogs_amd.window import replicas_in_sync
+        in_sync = bool(replicas_in_sync([p.grad for p in params]))
+        exchange["replicas_in_sync"] = in_sync
+        if not in_sync:       # how far apart: max |g - g of rank 0| over the ranks (a collective that sums in a rank-dependent order
+            worst = 0.0       # would show up here as a last-bit difference, a broken exchange as something large)
+            for p in params:
+                ref = p.grad.detach().clone()
+                if rehearsal:
+                    h = ref.cpu(); dist.broadcast(h, src=0); ref = h.to(dev)
+                else:
+                    dist.broadcast(ref, src=0)
+                d = (p.grad - ref).abs().max().reshape(1)
+                if rehearsal:
+                    h = d.cpu(); dist.all_reduce(h, op=dist.ReduceOp.MAX); d = h
+                else:
+                    dist.all_reduce(d, op=dist.ReduceOp.MAX)
+                worst = max(worst, float(d.item()) / max(float(ref.abs().max().item()), 1e-30))
+            exchange["max_relative_difference_between_ranks"] = worst
 
     # ---- per-kernel time, live, with HIP events on the launch stream (separate from the timed region)
     roof = None
@@ -520,7 +551,10 @@ def main():
             traceback.print_exc()
             slam = {"error": repr(e)[:300]}
 
+    comm = None
     if distributed:
+        comm = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "devices_visible": n_dev,
+                "device": torch.cuda.get_device_name(dev)}
         dist.barrier()
         dist.destroy_process_group()
 
@@ -544,7 +578,14 @@ def main():
         }
         if exchange is not None:
             line["exchange"] = exchange
+            line["replicas_in_sync"] = exchange["replicas_in_sync"]
+        if comm is not None:
+            line["comm"] = comm
         print(json.dumps(line), flush=True)
+    if exchange is not None and not exchange["replicas_in_sync"]:
+        # (every rank computed the same verdict from the same MIN / MAX reductions: all of them leave non-zero)
+        print(f"[bench] rank {rank}: the ranks hold DIFFERENT reduced gradients after the all-reduce", file=sys.stderr, flush=True)
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

@@ -104,6 +104,11 @@ __device__ __forceinline__ Rec fetch(const BlendArgs& a, uint32_t gid_uniform) {
 //     EXEC = all
 // One asm block (the compiler must never see a narrowed EXEC): 17 scalar + 23 vector instructions per survivor, 19 + 25
 // while a pixel of the quadrant is still in front of half its light (TOUCH: only then can T (1 - alpha) exceed 0.5).
+#ifdef MGS_FWD_LDSQ
+#define MGS_RECOP "v"          // the survivor's record comes back from the per-wave LDS queue in vector registers
+#else
+#define MGS_RECOP "s"          // ... or through the scalar cache in scalar registers
+#endif
 template <bool TOUCH>
 __device__ __forceinline__ void blend_one(unsigned long long& live, unsigned long long& mask, float& T, uint32_t& last, float& C0, float& C1, float& C2,
                                       float& D, const Rec& g, float power, float alpha, uint32_t pos, int j,
@@ -135,7 +140,7 @@ __device__ __forceinline__ void blend_one(unsigned long long& live, unsigned lon
             : [live] "+s"(live), [mask] "+s"(mask), [T] "+v"(T), [last] "+v"(last), [C0] "+v"(C0), [C1] "+v"(C1), [C2] "+v"(C2), [D] "+v"(D),
               [w] "=&v"(w), [cnt] "=&s"(cnt), [tc] "+v"(touched_cnt)
             : [power] "v"(power), [alpha] "v"(alpha), [tt] "v"(test_T), [amin] "s"(1.0f / 255.0f), [tmin] "s"(0.0001f),
-              [pos] "s"(pos), [cr] "s"(g.r), [cg] "s"(g.g), [cb] "s"(g.b), [cz] "s"(g.z), [j] "s"(j)
+              [pos] "s"(pos), [cr] MGS_RECOP(g.r), [cg] MGS_RECOP(g.g), [cb] MGS_RECOP(g.b), [cz] MGS_RECOP(g.z), [j] "s"(j)
             : "vcc", "scc", "m0");
     } else {
         asm volatile(
@@ -157,7 +162,7 @@ __device__ __forceinline__ void blend_one(unsigned long long& live, unsigned lon
             : [live] "+s"(live), [mask] "+s"(mask), [T] "+v"(T), [last] "+v"(last), [C0] "+v"(C0), [C1] "+v"(C1), [C2] "+v"(C2), [D] "+v"(D),
               [w] "=&v"(w)
             : [power] "v"(power), [alpha] "v"(alpha), [tt] "v"(test_T), [amin] "s"(1.0f / 255.0f), [tmin] "s"(0.0001f),
-              [pos] "s"(pos), [cr] "s"(g.r), [cg] "s"(g.g), [cb] "s"(g.b), [cz] "s"(g.z)
+              [pos] "s"(pos), [cr] MGS_RECOP(g.r), [cg] MGS_RECOP(g.g), [cb] MGS_RECOP(g.b), [cz] MGS_RECOP(g.z)
             : "vcc", "scc");
     }
 }
@@ -189,6 +194,15 @@ __global__ void __launch_bounds__(256) blend_forward_kernel(BlendArgs a, float* 
 
     uint32_t gid_n = 0;
     float4 box_n = make_float4(0.f, 0.f, -1.f, -1.f), ell_n = make_float4(0.f, 0.f, 0.f, 0.f);
+#ifdef MGS_FWD_LDSQ
+    // EXPERIMENT ("measured and rejected"): the whole 64-byte record of every instance of the next step is
+    // prefetched by its lane (the same cache line the cull data comes from) and parked in a per-wave LDS queue; a survivor's
+    // record then comes back with broadcast ds_reads instead of a dependent scalar-cache round trip per survivor.
+    __shared__ __attribute__((aligned(16))) float4 s_queue[4][WAVE][3];
+    float4 c1_n = make_float4(0.f, 0.f, 0.f, 0.f), c2_n = c1_n;
+    float4* const my_entry = &s_queue[wave][lane][0];
+    const uint32_t q_base = (uint32_t)(uintptr_t)&s_queue[wave][0][0];      // LDS byte address of this wave's queue
+#endif
     auto prefetch = [&](uint32_t i) {               // next step's index + cull data, issued one step ahead
         gid_n = 0;
         box_n = make_float4(0.f, 0.f, -1.f, -1.f);
@@ -196,6 +210,10 @@ __global__ void __launch_bounds__(256) blend_forward_kernel(BlendArgs a, float* 
             gid_n = a.point_list[i];
             box_n = a.rec[(size_t)gid_n * 4];
             ell_n = a.rec[(size_t)gid_n * 4 + 3];
+#ifdef MGS_FWD_LDSQ
+            c1_n = a.rec[(size_t)gid_n * 4 + 1];
+            c2_n = a.rec[(size_t)gid_n * 4 + 2];
+#endif
         }
     };
     auto walk_step = [&](auto touch_tag, uint32_t base, uint32_t gid_l, unsigned long long mask) {
@@ -205,8 +223,18 @@ __global__ void __launch_bounds__(256) blend_forward_kernel(BlendArgs a, float* 
         while (mask) {
             const int j = __builtin_ctzll(mask);
             mask &= ~(1ull << j);
+#ifdef MGS_FWD_LDSQ
+            float4 e0, e1, e2;                      // uniform address: three broadcast reads
+            {
+                const uint32_t ad = q_base + (uint32_t)j * 48u;
+                asm volatile("ds_read_b64 %0, %3\n\tds_read_b128 %1, %3 offset:16\n\tds_read_b128 %2, %3 offset:32\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(*reinterpret_cast<float2*>(&e0)), "=&v"(e1), "=&v"(e2) : "v"(ad) : "memory");
+            }
+            const Rec g{e0.x, e0.y, e1.x, e1.y, e1.z, e1.w, e2.x, e2.y, e2.z, e2.w};
+#else
             const uint32_t gid = bcast(gid_l, j);
             const Rec g = fetch(a, gid);
+#endif
             const float dx = g.px - pxf, dy = g.py - pyf;
             const float power = dx * (g.ca * dx + g.cb * dy) + (g.cc * dy) * dy;     // log2 of the Gaussian falloff
             const float alpha = fminf(0.99f, g.op * __builtin_amdgcn_exp2f(power));
@@ -220,6 +248,9 @@ __global__ void __launch_bounds__(256) blend_forward_kernel(BlendArgs a, float* 
     for (uint32_t base = range.x; base < range.y && live != 0ull; base += WAVE) {
         const uint32_t gid_l = gid_n;
         const float4 c = box_n, el = ell_n;
+#ifdef MGS_FWD_LDSQ
+        my_entry[0] = c; my_entry[1] = c1_n; my_entry[2] = c2_n;      // (the wave's own queue: LDS ops of a wave run in order)
+#endif
         prefetch(base + WAVE + lane);
         const unsigned long long mask = __builtin_amdgcn_ballot_w64(quadrant_hit(c, el, qx0, qy0, live));
         // a pixel counts as "touched" by an instance when T (1 - alpha) > 0.5: impossible once every live pixel has T <= 0.5
@@ -712,7 +743,11 @@ __global__ void __launch_bounds__(256) blend_backward_t_kernel(BlendArgs a, int 
             const bool act = (k_first + (uint32_t)j <= last) && !(power > 0.f) && !(alpha < 1.0f / 255.0f);
             if (__builtin_amdgcn_ballot_w64(act) == 0ull) return;
             const float a_eff = act ? alpha : 0.f;
+#ifdef MGS_EXP_IEEE_DIV
+            const float inv = 1.f / (1.f - a_eff);
+#else
             const float inv = __builtin_amdgcn_rcpf(1.f - a_eff);
+#endif
             const float Tn = T * inv;
             const float qq = __builtin_fmaf(g.z, gd, __builtin_fmaf(g.b, g2, __builtin_fmaf(g.g, g1, g.r * g0)));
             const float diff = qq - Bk;
@@ -733,9 +768,16 @@ __global__ void __launch_bounds__(256) blend_backward_t_kernel(BlendArgs a, int 
             const int j = 63 - __builtin_clzll(mask);
             mask &= ~(1ull << j);
             const Rec g = fetch(a, bcast(gid_l, j));
+#ifdef MGS_EXP_FETCH_ONCE
+            asm volatile("" ::"s"(g.r), "s"(g.g), "s"(g.b), "s"(g.z));      // the whole record in ONE scalar round trip
+#endif
             const float dx = g.px - pxf, dy = g.py - pyf;
             const float power = dx * (g.ca * dx + g.cb * dy) + (g.cc * dy) * dy;
+#ifdef MGS_EXP_PRECISE_EXP
+            const float G = exp2f(power);
+#else
             const float G = __builtin_amdgcn_exp2f(power);
+#endif
             apply(g, j, power, G, fminf(0.99f, g.op * G));
         }
     }

@@ -89,6 +89,11 @@ class _Plan:
         self.n_touched: List = []
         self.graphs = None              # (front, back) or (whole,) once captured
         self.iter_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        # pipelined exchange (WindowMapper.exchange = "per_keyframe"): one gradient bucket per owned keyframe, reduced on
+        # its own while the next keyframe renders; `slot_graphs`: one captured (render, loss, backward) per owned keyframe
+        self.pipelined = bool(mapper.sharded and mapper.exchange == "per_keyframe" and len(self.mine) > 1)
+        self.slot_flat = [torch.zeros(P * _GRAD_COLS, **f32) for _ in self.mine] if self.pipelined else []
+        self.slot_graphs = None
 
     def grad_view(self, col0: int, cols: int):
         P = self.P
@@ -143,6 +148,17 @@ class WindowMapper:
         self.stats = dict(captures=0, replays=0, eager_iters=0, capture_s=0.0, replay_s=0.0, replay_kf=0)
         self.time_replays = False        # measure the replay chunks (one synchronisation at either end of a chunk)
         self.coviz_log: List = []        # (map size, Gaussians dropped) of every covisibility prune
+        # How the Gaussian gradients cross the ranks (sharded only).
+        #   "bucket" (default): every rank sums its keyframes' gradients locally and ONE all-reduce follows the last backward --
+        #       the fewest bytes, nothing to overlap with.
+        #   "per_keyframe": with several keyframes per rank (window / world > 1) each owned keyframe's gradients are reduced on
+        #       their own, issued as soon as that keyframe's backward is queued, so the collective of keyframe k runs (on RCCL's
+        #       stream) while keyframe k + 1 renders; the reduced buckets are then added in keyframe order.  window / world times
+        #       the bytes: pays when a bucket's all-reduce takes about as long as a render (maps of millions of Gaussians), not
+        #       at SLAM sizes.  `overlap_exchange = False` issues the same collectives after the last backward instead: the same
+        #       arithmetic in the same order, hence bit-identical results -- the reference the overlapped schedule is tested against.
+        self.exchange = "bucket"
+        self.overlap_exchange = True
 
     # ---- per-keyframe optimiser state lives on the owning rank ------------------------------------------------------
     def _pose_optimizer(self, vp) -> PoseAdam:
@@ -192,16 +208,52 @@ class WindowMapper:
         self._plan = None
 
     # ---- the two halves of an iteration -----------------------------------------------------------------------------
-    def _front(self, p: _Plan, accumulate_stats: bool, parallel: bool):
-        """Renders + losses + ONE backward of the owned keyframes into the bucket, then the statistics launch."""
+    def _activations(self, p: _Plan):
         gmap, lib, P = self.gmap, _lib.load(), p.P
         with _device_guard(gmap._xyz.device):
             _lib.check(lib.mgs_activate_forward(P, p.sd, gmap._rotation.data_ptr(), gmap._scaling.data_ptr(),
                                                 gmap._opacity.data_ptr(), p.rot.data_ptr(), p.scales3.data_ptr(),
                                                 p.opac.data_ptr(), _stream()), "mgs_activate_forward")
-        # the five tensors the renders differentiate with respect to: leaves that CUT the graph at the activations (their
-        # backward is one explicit launch in `_back`, after the collectives)
-        cut = [t.detach().requires_grad_(True) for t in (gmap._xyz, gmap._rgb, p.opac, p.scales3, p.rot)]
+
+    def _cut(self, p: _Plan):
+        """The five tensors the renders differentiate with respect to: leaves that CUT the graph at the activations (their
+        backward is one explicit launch in `_back`, after the collectives)."""
+        gmap = self.gmap
+        return [t.detach().requires_grad_(True) for t in (gmap._xyz, gmap._rgb, p.opac, p.scales3, p.rot)]
+
+    def _render_slot(self, p: _Plan, j: int, fan):
+        """Forward of owned keyframe j: the full render + the fused loss value and gradients.  Returns what its backward needs."""
+        vp = p.vps[j]
+        xyz_k, feat_k, opac_k, sc_k, rot_k = fan
+        h = p.holders[j]
+        h.grad = None
+        color, radii, depth, n_touched = self._rasterize(vp, xyz_k, rot_k, sc_k, opac_k, feat_k, h)
+        lg = fused_losses.loss_grads(color, depth, None, vp, tracking=False, init=p.init)
+        p.lgs.append(lg)
+        p.radii.append(radii)
+        p.n_touched.append(n_touched)
+        return [color, depth], [lg.d_render, lg.d_depth]
+
+    @staticmethod
+    def _take_exposure_grads(vp, lg):
+        if lg.has_exposure:         # (added to what a pruning call left there, like autograd's accumulation)
+            for q, g in ((vp.exposure_a, lg.d_exposure_a), (vp.exposure_b, lg.d_exposure_b)):
+                q.grad = g if q.grad is None else q.grad + g
+
+    def _stats(self, p: _Plan, accumulate_stats: bool):
+        """Per-keyframe statistics, one launch (per-keyframe norm BEFORE any summation)."""
+        gmap = self.gmap
+        if accumulate_stats:            # single rank: straight into the map's running statistics, in keyframe order
+            norm, vis, maxr = gmap.xyz_gradient_accum, gmap.denom, gmap.max_radii_2d
+        else:
+            norm, vis, maxr = p.grad_view(14, 1), p.grad_view(15, 1), p.maxr
+        window_stats([h.grad for h in p.holders], p.radii, p.n_touched, norm, vis, maxr, accumulate_stats, p.bits)
+
+    def _front(self, p: _Plan, accumulate_stats: bool, parallel: bool):
+        """Renders + losses + ONE backward of the owned keyframes into the bucket, then the statistics launch."""
+        P = p.P
+        self._activations(p)
+        cut = self._cut(p)
         p.lgs, p.radii, p.n_touched = [], [], []
         if not p.mine:
             p.bucket[:P * _GRAD_COLS].zero_()
@@ -210,20 +262,13 @@ class WindowMapper:
             streams = self._kf_streams(len(p.mine)) if (parallel and len(p.mine) > 1) else None
             main = torch.cuda.current_stream() if streams else None
             outs, grads = [], []
-            for j, vp in enumerate(p.vps):
+            for j in range(len(p.vps)):
                 if streams:
                     streams[j].wait_stream(main)
                 with (torch.cuda.stream(streams[j]) if streams else contextlib.nullcontext()):
-                    xyz_k, feat_k, opac_k, sc_k, rot_k = fans[j]
-                    h = p.holders[j]
-                    h.grad = None
-                    color, radii, depth, n_touched = self._rasterize(vp, xyz_k, rot_k, sc_k, opac_k, feat_k, h)
-                    lg = fused_losses.loss_grads(color, depth, None, vp, tracking=False, init=p.init)
-                outs += [color, depth]
-                grads += [lg.d_render, lg.d_depth]
-                p.lgs.append(lg)
-                p.radii.append(radii)
-                p.n_touched.append(n_touched)
+                    o, g = self._render_slot(p, j, fans[j])
+                outs += o
+                grads += g
             # (no join before the backward: every keyframe's backward runs on the stream of its forward, behind it, and the
             #  node that adds the gradients up waits for all of them)
             torch.autograd.backward(outs, grads)
@@ -231,15 +276,39 @@ class WindowMapper:
                 for st in streams:
                     main.wait_stream(st)
             for vp, lg in zip(p.vps, p.lgs):
-                if lg.has_exposure:         # (added to what a pruning call left there, like autograd's accumulation)
-                    for q, g in ((vp.exposure_a, lg.d_exposure_a), (vp.exposure_b, lg.d_exposure_b)):
-                        q.grad = g if q.grad is None else q.grad + g
-        # ---- per-keyframe statistics, one launch (per-keyframe norm BEFORE any summation)
-        if accumulate_stats:            # single rank: straight into the map's running statistics, in keyframe order
-            norm, vis, maxr = gmap.xyz_gradient_accum, gmap.denom, gmap.max_radii_2d
+                self._take_exposure_grads(vp, lg)
+        self._stats(p, accumulate_stats)
+
+    # ---- pipelined exchange: one bucket per owned keyframe, its all-reduce behind the next keyframe's render ------------
+    def _slot(self, p: _Plan, j: int):
+        """Render + loss + backward of owned keyframe j alone; its map gradients land in ``p.slot_flat[j]`` (bucket layout)."""
+        fan = fan_out(1, *self._cut(p), out=p.slot_flat[j])[0]
+        o, g = self._render_slot(p, j, fan)
+        torch.autograd.backward(o, g)
+        self._take_exposure_grads(p.vps[j], p.lgs[-1])
+
+    def _front_pipelined(self, p: _Plan):
+        """The front half with ``exchange = "per_keyframe"``: activations, then per owned keyframe (render, loss, backward) and
+        the all-reduce of ITS bucket -- asynchronous, so that it runs behind the next keyframe's kernels -- then the reduced
+        buckets added up in keyframe order and the statistics launch.  The two statistics columns and the all-gather follow in
+        `_exchange`.  Captured plans replay one graph per keyframe (`p.slot_graphs`) and one for the tail."""
+        if p.slot_graphs is None:
+            self._activations(p)
+            p.lgs, p.radii, p.n_touched = [], [], []
+            produce = lambda j: self._slot(p, j)                    # noqa: E731
         else:
-            norm, vis, maxr = p.grad_view(14, 1), p.grad_view(15, 1), p.maxr
-        window_stats([h.grad for h in p.holders], p.radii, p.n_touched, norm, vis, maxr, accumulate_stats, p.bits)
+            p.slot_graphs[0].replay()                                # (the activations)
+            produce = lambda j: p.slot_graphs[1 + j].replay()        # noqa: E731
+        W.pipelined_all_reduce(len(p.mine), produce, p.slot_flat, group=self.group, overlap=self.overlap_exchange)
+        if p.slot_graphs is None:
+            self._sum_slots(p)
+        else:
+            p.slot_graphs[-1].replay()
+
+    def _sum_slots(self, p: _Plan):
+        from .gaussian_optim import sum_buffers
+        sum_buffers(p.slot_flat, out=p.bucket[:p.P * _GRAD_COLS])          # fixed order: keyframe 0, 1, ... of this rank
+        self._stats(p, accumulate_stats=False)
 
     def _rasterize(self, vp, xyz, rot, scales3, opac, feat, holder):
         """The rasteriser call of ``render()`` (/root/reference/gaussian_splatting/gaussian_renderer/__init__.py:52-156)."""
@@ -255,8 +324,10 @@ class WindowMapper:
             theta=vp.cam_rot_delta, rho=vp.cam_trans_delta)
         return color, radii, depth, n_touched
 
-    def _exchange(self, p: _Plan, grads: bool = True):
-        """The collectives of one iteration: SUM of the bucket, one all-gather of MAX radii + visibility bits."""
+    def _exchange(self, p: _Plan, grads: bool = True, reduced: bool = False):
+        """The collectives of one iteration: SUM of the bucket, one all-gather of MAX radii + visibility bits.
+        ``reduced``: the gradient columns were reduced keyframe by keyframe already (`_front_pipelined`); the two
+        statistics columns remain."""
         if not self.sharded:
             return
         on_gpu = torch.device(self.gmap.device).type == "cuda"
@@ -264,7 +335,8 @@ class WindowMapper:
             torch.cuda.synchronize()
         t0 = time.perf_counter()
         if grads:
-            W.all_reduce_(p.bucket, group=self.group)
+            # (pipelined plans reduced the gradient columns keyframe by keyframe already: the two statistics columns remain)
+            W.all_reduce_(p.bucket[p.P * _GRAD_COLS:] if reduced else p.bucket, group=self.group)
         W.all_gather_into_(p.gout.view(-1), p.gin, group=self.group)
         if self.time_comm:
             if on_gpu:
@@ -321,11 +393,24 @@ class WindowMapper:
             self._pool = torch.cuda.graph_pool_handle()
         par = True if self.parallel_keyframes is None else bool(self.parallel_keyframes)
         single = not self.sharded
-        g1 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g1, pool=self._pool):
-            self._front(p, accumulate_stats=single, parallel=par)
-            if single:
-                self._back(p, viewpoints, pose_steps, lr_update)
+        if p.pipelined:
+            # activations | one graph per owned keyframe | slot sum + statistics; the collectives run between them
+            p.lgs, p.radii, p.n_touched = [], [], []
+            graphs = []
+            for body in [lambda: self._activations(p)] + [(lambda j=j: self._slot(p, j)) for j in range(len(p.mine))] + \
+                    [lambda: self._sum_slots(p)]:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=self._pool):
+                    body()
+                graphs.append(g)
+            p.slot_graphs = graphs
+            g1 = None
+        else:
+            g1 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g1, pool=self._pool):
+                self._front(p, accumulate_stats=single, parallel=par)
+                if single:
+                    self._back(p, viewpoints, pose_steps, lr_update)
         if single:
             p.graphs = (g1,)
         else:
@@ -345,8 +430,11 @@ class WindowMapper:
                 p.graphs[0].replay()
         else:
             for _ in range(n):
-                p.graphs[0].replay()
-                self._exchange(p)
+                if p.pipelined:
+                    self._front_pipelined(p)
+                else:
+                    p.graphs[0].replay()
+                self._exchange(p, reduced=p.pipelined)
                 p.graphs[1].replay()
         if self.time_replays:
             torch.cuda.synchronize()
@@ -409,12 +497,16 @@ class WindowMapper:
     def _iterate_eager(self, p: _Plan, viewpoints, pose_steps, lr_update, surgery, parallel) -> bool:
         self.nr_iters += 1
         self.stats["eager_iters"] += 1
-        self._front(p, accumulate_stats=not self.sharded, parallel=parallel)
+        reduced = p.pipelined and self._carry is None
+        if reduced:
+            self._front_pipelined(p)
+        else:       # (an iteration that takes in a pruning call's carried gradients uses the plain bucket: they join it before the all-reduce)
+            self._front(p, accumulate_stats=not self.sharded, parallel=parallel)
         if self._carry is not None:
             if self._carry.shape[0] == p.P * _GRAD_COLS:
                 p.bucket[:p.P * _GRAD_COLS] += self._carry
             self._carry = None
-        self._exchange(p)
+        self._exchange(p, reduced=reduced)
         split = self._back(p, viewpoints, pose_steps, lr_update, surgery)
         self._zero_grads(p if not split else None, viewpoints)
         return split

@@ -53,6 +53,25 @@ def all_gather_into_(out: torch.Tensor, inp: torch.Tensor, group=None):
     dist.all_gather_into_tensor(out, inp, group=group)
 
 
+def pipelined_all_reduce(n_slots: int, produce, buffers: Sequence[torch.Tensor], group=None, overlap: bool = True) -> None:
+    """SUM-all-reduce ``buffers[j]`` for every slot j, where ``produce(j)`` queues the work that fills ``buffers[j]`` (one
+    owned keyframe's render + backward).  ``overlap``: slot j's collective is issued right behind ``produce(j)``,
+    asynchronously, so that it runs while ``produce(j + 1)`` executes (RCCL: on the communicator's stream, ordered behind
+    the producer by an event); otherwise all collectives are issued after the last producer.  Same collectives, same data,
+    same order either way -- the results are bit-identical, only the timing differs.  Returns when every collective has been
+    waited for (the caller's stream then sees the reduced buffers)."""
+    works = []
+    for j in range(n_slots):
+        produce(j)
+        if overlap:
+            works.append(all_reduce_(buffers[j], group=group, async_op=True))
+    if not overlap:
+        works = [all_reduce_(b, group=group, async_op=True) for b in buffers]
+    for w in works:
+        if w is not None:
+            w.wait()
+
+
 # Above this many bytes the gradients are reduced in place, tensor by tensor (5 large collectives),
 # instead of being packed into one bucket: at 2 M Gaussians the pack + unpack copies (2 x 96 MB) cost
 # more than four extra collective launches; small SLAM maps (a few MB) keep the single latency-bound message.

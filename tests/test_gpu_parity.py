@@ -201,8 +201,20 @@ def test_c2_100k_mapping_loss_gradients(native_lib):
                                       want_ambiguous=True)
     ok = ~oout.aux["ambiguous"]
     assert (color.detach().cpu() - oout.color).abs().amax(0)[ok].max() <= 1e-4
-    rep = _check_grads(grads, ograds)
+    # (a sign-valued upstream gradient makes every per-Gaussian sum a cancellation of equal-magnitude terms: the two float32
+    #  implementations -- different summation orders -- sit ~1e-4 apart in relative L2 where uniform noise gives ~1e-6; the
+    #  bar of north_star is rtol 1e-3)
+    rep = _check_grads(grads, ograds, l2_tol=5e-4)
     print({k: (f"{a:.2e}", f"{b:.1e}") for k, (a, b) in rep.items()})
+    # ... and that it IS rounding, not a systematic difference: against the float64 oracle the HIP gradients are no further
+    # off than the float32 oracle's own
+    _, g64 = rasterize_autograd(inp, scene_settings(sc, OracleSettings), g_color, g_depth, dtype=torch.float64)
+    for k in ("means3D", "scales", "rotations", "opacities", "colors_precomp"):
+        ref = g64[k].double()
+        e_hip = ((grads[k].reshape(ref.shape).double() - ref).norm() / ref.norm()).item()
+        e_o32 = ((ograds[k].reshape(ref.shape).double() - ref).norm() / ref.norm()).item()
+        print(f"  {k}: vs float64 oracle -- HIP {e_hip:.2e}, float32 oracle {e_o32:.2e}")
+        assert e_hip <= max(3.0 * e_o32, 1e-5), (k, e_hip, e_o32)
 
 
 @pytest.mark.parametrize("pose_only", [False, True])

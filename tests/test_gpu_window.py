@@ -182,7 +182,7 @@ def _c4_setup(dev, n_kf, intrinsics, n_gaussians, downsample):
     return frames, intr, gmap
 
 
-def _run_c4(rank, world, port, out, use_graph, n_kf, intrinsics, n_gaussians, downsample, iters, tag):
+def _run_c4(rank, world, port, out, use_graph, n_kf, intrinsics, n_gaussians, downsample, iters, tag, exchange="bucket"):
     """One mapping call over the whole window (BASELINE config C4 when 8 keyframes at 1200x680), sharded over `world`."""
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
@@ -197,6 +197,7 @@ def _run_c4(rank, world, port, out, use_graph, n_kf, intrinsics, n_gaussians, do
     before = [p.detach().clone() for p in gmap.params()]
     mapper = WindowMapper(gmap, intr, torch.zeros(3, device=dev), window_size=n_kf, use_graph=use_graph)
     mapper.map_surgery = False
+    mapper.exchange = exchange
     mapper.optimize_map(frames, iters=iters)
     in_sync = replicas_in_sync(gmap.params() + [gmap.xyz_gradient_accum, gmap.denom, gmap.max_radii_2d] + gmap.optimizer.exp_avg)
     mapper.sync_poses(frames)
@@ -266,6 +267,25 @@ def test_c4_window_two_ranks_match_one_rank_captured(native_lib, tmp_path):
         for a, b in zip(pa, pb):
             assert torch.equal(a, b)                               # after sync_poses
     assert r0["mstats"]["captures"] == 1 and r0["mstats"]["replays"] == iters - 1
+    _check_windows_agree(r0, one, n_kf, iters)
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_pipelined_exchange_window_matches_single_process(native_lib, tmp_path, use_graph):
+    """`exchange = "per_keyframe"`: with two keyframes per rank every owned keyframe's gradients are all-reduced on their own,
+    issued behind its backward while the next keyframe renders (eager: one (render, loss, backward) per keyframe; captured: one
+    graph per keyframe, the collectives between the replays), then added in keyframe order.  Against the single-process
+    window the result differs by summation order only; the two replicas hold the same bits."""
+    out, iters, n_kf = str(tmp_path / "pk"), 10, 4
+    args = (n_kf, "fr3_office", 20000, 8, iters)
+    mp.spawn(_run_c4, args=(2, _free_port(), out, use_graph) + args + ("p", "per_keyframe"), nprocs=2, join=True)
+    mp.spawn(_run_c4, args=(1, 0, out, use_graph) + args + ("p",), nprocs=1, join=True)
+    r0, r1, one = (torch.load(f"{out}.p.{w}.{r}") for w, r in ((2, 0), (2, 1), (1, 0)))
+    assert r0["in_sync"] and r1["in_sync"]
+    for a, b in zip(r0["params"], r1["params"]):
+        assert torch.equal(a, b)
+    if use_graph:
+        assert r0["mstats"]["captures"] == 1 and r0["mstats"]["replays"] == iters - 1
     _check_windows_agree(r0, one, n_kf, iters)
 
 

@@ -224,3 +224,57 @@ def test_flat_view_finds_back_to_back_gradients():
     assert flat_view([views[0], torch.zeros(P, 3)]) is None  # another storage
     assert flat_view([views[0].t()]) is None               # not contiguous
     assert flat_view([]) is None
+
+
+def _pipeline_worker(rank, world, port, P, n_kf, out):
+    """The per-keyframe exchange schedule on deterministic stand-in gradients: overlapped (collective j issued right behind
+    producer j) against the same collectives issued after the last producer, and against the one-bucket exchange."""
+    sys.path.insert(0, ROOT)
+    from monogs_amd.window import all_reduce_, pipelined_all_reduce, shard_keyframes
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = shard_keyframes(n_kf, rank, world)
+    res = {}
+    for overlap in (True, False):
+        bufs = [torch.zeros(P * 14) for _ in mine]
+        order = []
+
+        def produce(j):
+            order.append(j)
+            gs = _keyframe_grads(P, mine[j])[0]
+            bufs[j].copy_(torch.cat([g.t().reshape(-1) for g in gs] + [torch.zeros(P * 2)]))      # [cols][P], as the bucket
+        pipelined_all_reduce(len(mine), produce, bufs, overlap=overlap)
+        total = bufs[0].clone()
+        for b in bufs[1:]:               # fixed order: owned keyframe 0, 1, ...
+            total += b
+        res[overlap] = (total, list(order))
+    bucket = torch.zeros(P * 14)
+    for k in mine:                       # the one-bucket exchange: local sum first, one all-reduce
+        gs = _keyframe_grads(P, k)[0]
+        bucket += torch.cat([g.t().reshape(-1) for g in gs] + [torch.zeros(P * 2)])
+    all_reduce_(bucket)
+    torch.save(dict(overlap=res[True][0], serial=res[False][0], order=res[True][1], bucket=bucket), f"{out}.{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_pipelined_exchange_is_bit_identical_to_the_unpipelined_schedule(tmp_path):
+    """`WindowMapper.exchange = "per_keyframe"` (window / world > 1): keyframe k's bucket is all-reduced while keyframe k + 1
+    renders.  Issuing the collectives early must change nothing: overlapped == issued-after-the-last-producer, bit for bit, on
+    both ranks; both ranks hold the same bits; and the result equals the one-bucket exchange up to the association of the sum
+    ((g0 + g1) + (g2 + g3) across ranks first, against (g0 + g2) + (g1 + g3) locally first)."""
+    P, n_kf, world = 3000, 6, 2
+    out = str(tmp_path / "pipe")
+    mp.spawn(_pipeline_worker, args=(world, _free_port(), P, n_kf, out), nprocs=world, join=True)
+    r0, r1 = torch.load(out + ".0"), torch.load(out + ".1")
+    assert r0["order"] == [0, 1, 2]
+    for r in (r0, r1):
+        assert torch.equal(r["overlap"], r["serial"])
+    assert torch.equal(r0["overlap"], r1["overlap"]) and torch.equal(r0["bucket"], r1["bucket"])
+    ref = torch.zeros(P * 14)
+    for k in range(n_kf):
+        ref += torch.cat([g.t().reshape(-1) for g in _keyframe_grads(P, k)[0]] + [torch.zeros(P * 2)])
+    for name in ("overlap", "bucket"):
+        assert torch.allclose(r0[name], ref, rtol=1e-5, atol=1e-5), name
+    assert not torch.equal(r0["overlap"], r0["bucket"]) or True      # (association differs; equality is not required)

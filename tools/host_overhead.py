@@ -40,6 +40,33 @@ for _ in range(n):
     step()
 torch.cuda.synchronize()
 print(f"eager exact-count (one count read-back + sync per forward, as upstream): {(time.perf_counter() - t0) / n * 1e3:.3f} ms / iteration")
+# where the exact path's wall time goes: host stamps around the three calls of an iteration (the read-back inside render()
+# waits for the GPU to drain everything queued so far, so `render` contains the previous iteration's backward on the device)
+acc = [0.0, 0.0, 0.0, 0.0]
+for _ in range(n):
+    a = time.perf_counter()
+    pkg = render(vp, intr, *P, bg)
+    b = time.perf_counter()
+    loss = fused_losses.get_loss_mapping(pkg["render"], pkg["depth"], vp)
+    c = time.perf_counter()
+    loss.backward()
+    d = time.perf_counter()
+    for p in P:
+        p.grad = None
+    e = time.perf_counter()
+    for i, v in enumerate((b - a, c - b, d - c, e - d)):
+        acc[i] += v
+torch.cuda.synchronize()
+print("exact-count host stamps per iteration: render %.3f ms (contains the count read-back), loss forward %.3f, loss.backward() %.3f, "
+      "grad reset %.3f" % tuple(1e3 * v / n for v in acc))
+pr = cProfile.Profile()
+pr.enable()
+for _ in range(n):
+    step()
+torch.cuda.synchronize()
+pr.disable()
+print("---- cProfile, exact-count path")
+pstats.Stats(pr).sort_stats("tottime").print_stats(16)
 # capacity mode: nothing synchronises, so the wall time per iteration is max(host time, GPU time); the GPU time of the same
 # iteration comes from events around a burst the host has queued ahead
 from monogs_amd import rasterizer as R

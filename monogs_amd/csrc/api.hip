@@ -239,11 +239,12 @@ static int forward_render_impl(const mgs_camera* cam, int32_t P, uint64_t R, boo
     if (int rc = launch_duplicate(*cam, P, g, b, capacity ? R : (R > 0 ? 0xFFFFFFFFull : 0ull), n_touched, img, R,
                                   tile_bits(W, H), cap ? b.count : nullptr, overflow, s)) return rc;
     tm.mark();
-    if (int rc = launch_sort(g, b, R, tile_bits(W, H), s, n_dev, (cam->flags & MGS_FLAG_EXCLUSIVE_DEVICE) != 0)) return rc;
+    // (the sort's final pass writes the per-tile ranges: no ranges launch since round 4)
+    if (int rc = launch_sort(g, b, R, tile_bits(W, H), s, n_dev, (cam->flags & MGS_FLAG_EXCLUSIVE_DEVICE) != 0, img.ranges)) return rc;
     tm.mark();
-    if (int rc = launch_ranges(b, R, img, tiles_x(W) * tiles_y(H), tile_bits(W, H), s, n_dev, overflow)) return rc;
     tm.mark();
-    if (int rc = launch_blend_forward(*cam, g, b, img, out_color, out_depth, out_opacity, n_touched, s)) return rc;
+    if (int rc = launch_blend_forward(*cam, g, b, img, out_color, out_depth, out_opacity, n_touched,
+                                      R > 0 ? radix_error_flag(b.sort_temp, R, tile_bits(W, H)) : nullptr, overflow, s)) return rc;
     tm.mark();
     if (timing) {
         tm.sync();

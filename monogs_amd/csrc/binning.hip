@@ -199,10 +199,12 @@ __global__ void __launch_bounds__(256) duplicate_kernel(int P, const uint2* __re
         count[1] = R > r_cap ? 1u : 0u;
     }
     // status word of this forward (see MGS_STATUS_* in monogs_raster.h): capacity overflow | depth-sort look-back timeout;
-    // ranges_kernel adds the tile sort's flag
+    // blend_forward_kernel adds the tile sort's flag
     if (i == 0 && overflow)
         overflow[0] = (count ? count[1] : 0u) | (depth_bad ? (uint32_t)MGS_STATUS_DEPTH_SORT_TIMEOUT : 0u);
-    if (i < ntiles) ranges[i] = make_uint2(0u, 0u);      // empty-tile default (was a memset)
+    // empty-tile default, in the form the tile sort's final pass takes its minima / maxima over (blend_forward_kernel turns
+    // what is still {~0, 0} afterwards into {0, 0})
+    if (i < ntiles) ranges[i] = make_uint2(0xFFFFFFFFu, 0u);
     if (i < P) n_touched[i] = 0;                         // (was a memset)
     uint32_t idx = 0, nt = 0, off = 0;
     int x0 = 0, y0 = 0, x1 = 0;
@@ -425,49 +427,19 @@ int launch_depth_sort(const GeometryState& g, int P, bool payload, hipStream_t s
 }
 
 int launch_sort(const GeometryState& g, const BinningState& b, uint64_t R, int bits, hipStream_t s, const uint32_t* n_dev,
-                bool exclusive) {
+                bool exclusive, uint2* ranges) {
     if (R == 0) return 0;
     // the scratch was cleared by duplicate_kernel, which also counted the digits of the keys it emitted (small sorts; the
     // same predicate as launch_duplicate's `count_digits` -- R > 0 implies P > 0, forward_render_impl)
     const bool counted = bits <= 16 && radix_wants_hist(R) && g.tile_hist != nullptr;
     return radix_sort_pairs(b.keys_a, b.vals_a, b.keys_b, b.vals_b, R, bits, b.sort_temp, s, n_dev, true, nullptr, nullptr,
-                            counted ? g.tile_hist : nullptr, false, exclusive);
+                            counted ? g.tile_hist : nullptr, false, exclusive, ranges);
 }
 
 // ------------------------------------------------------------------------------------------------
-// tile ranges
+// tile ranges: written by the tile sort's final pass (radix_sort.hip, RsPassArgs::ranges) since round 4 -- the kernel that
+// compared neighbouring sorted keys (one launch, 4 R bytes of reads) is gone; blend_forward_kernel checks the sort's error
+// words and normalises the empty tiles.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) ranges_kernel(uint64_t R, const uint32_t* __restrict__ n_dev,
-                                                     const uint32_t* __restrict__ keys, uint2* ranges,
-                                                     const uint32_t* __restrict__ sort_err, uint32_t* __restrict__ status) {
-    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    // a tile sort whose look-back timed out: keys[] is partly unwritten (arbitrary tile ids): leave every range empty
-    const bool sort_bad = radix_failed(sort_err) != 0u;
-    if (i == 0 && status && sort_bad) atomicOr(status, (uint32_t)MGS_STATUS_TILE_SORT_TIMEOUT);
-    if (sort_bad) return;
-    if (n_dev) R = min(R, (uint64_t)n_dev[0]);
-    if (i >= R) return;
-    const uint32_t t = keys[i];
-    if (i == 0) {
-        ranges[t].x = 0;
-    } else {
-        const uint32_t tp = keys[i - 1];
-        if (t != tp) {
-            ranges[tp].y = (uint32_t)i;
-            ranges[t].x = (uint32_t)i;
-        }
-    }
-    if (i == R - 1) ranges[t].y = (uint32_t)R;
-}
-
-int launch_ranges(const BinningState& b, uint64_t R, const ImageState& img, int ntiles, int sort_bits, hipStream_t s,
-                  const uint32_t* n_dev, uint32_t* status) {
-    (void)ntiles;        // the ranges were zeroed by duplicate_kernel
-    if (R == 0) return 0;
-    hipLaunchKernelGGL(ranges_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, R, n_dev, b.keys_sorted,
-                       img.ranges, radix_error_flag(b.sort_temp, R, sort_bits), status);
-    MGS_HIP(hipGetLastError());
-    return 0;
-}
 
 }  // namespace mgs

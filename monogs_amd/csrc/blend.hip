@@ -12,10 +12,10 @@
 //      64-byte record, {px, py, ex, ey};
 //   2. lane l tests the alpha >= 1/255 bounding box (px +- ex, py +- ey) against the wave's quadrant;
 //      __ballot compacts the survivors into a 64-bit mask held in scalar registers;
-//   3. the wave pops survivors off the mask; ONE v_readlane fetches the survivor's Gaussian index and
-//      the rest of its record arrives through the scalar cache (s_load_dwordx8 + s_load_dwordx4) --
-//      all 64 lanes (pixels) then evaluate it with SGPR operands.
-// No LDS, no barriers; a quadrant whose pixels are all saturated retires early.
+//   3. the wave pops survivors off the mask; the survivor's record arrives -- forward: with broadcast reads from a
+//      per-wave LDS queue that the lanes filled with the records they prefetched; backward: through the scalar cache
+//      (v_readlane of the index, s_load_dwordx2 + s_load_dwordx8) -- and all 64 lanes (pixels) evaluate it.
+// No barriers; a quadrant whose pixels are all saturated retires early.
 // Skipping an instance for a whole quadrant never changes a pixel: every skipped pair has
 // alpha < 1/255 and the per-pixel rule would have skipped it too.
 #include "common.h"
@@ -104,11 +104,7 @@ __device__ __forceinline__ Rec fetch(const BlendArgs& a, uint32_t gid_uniform) {
 //     EXEC = all
 // One asm block (the compiler must never see a narrowed EXEC): 17 scalar + 23 vector instructions per survivor, 19 + 25
 // while a pixel of the quadrant is still in front of half its light (TOUCH: only then can T (1 - alpha) exceed 0.5).
-#ifdef MGS_FWD_LDSQ
 #define MGS_RECOP "v"          // the survivor's record comes back from the per-wave LDS queue in vector registers
-#else
-#define MGS_RECOP "s"          // ... or through the scalar cache in scalar registers
-#endif
 template <bool TOUCH>
 __device__ __forceinline__ void blend_one(unsigned long long& live, unsigned long long& mask, float& T, uint32_t& last, float& C0, float& C1, float& C2,
                                       float& D, const Rec& g, float power, float alpha, uint32_t pos, int j,
@@ -172,7 +168,10 @@ __global__ void __launch_bounds__(256) blend_forward_kernel(BlendArgs a, float* 
                                                             float* __restrict__ out_opacity,
                                                             float* __restrict__ final_T,
                                                             uint32_t* __restrict__ n_contrib,
-                                                            int32_t* __restrict__ n_touched) {
+                                                            int32_t* __restrict__ n_touched,
+                                                            uint2* __restrict__ ranges_rw,
+                                                            const uint32_t* __restrict__ sort_err,
+                                                            uint32_t* __restrict__ status) {
     const int tile = blockIdx.x;
     const int tx = tile % a.gx, ty = tile / a.gx;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -181,7 +180,19 @@ __global__ void __launch_bounds__(256) blend_forward_kernel(BlendArgs a, float* 
     const bool inside = pxi < a.W && pyi < a.H;
     const float pxf = (float)pxi, pyf = (float)pyi;
     const float qx0 = (float)qx0i, qy0 = (float)qy0i;
-    const uint2 range = a.ranges[tile];
+    // The tile's range as the tile sort's final pass left it: {first, last + 1} of the tile's instances, or the preset {~0, 0}
+    // of a tile nothing landed in.  A tile sort whose look-back timed out left the instance list partly unwritten (arbitrary
+    // indices): then every tile is empty, and the forward's status word says why.  Either way the table is rewritten in its
+    // canonical form ({0, 0} for an empty tile) for the backward and for whoever reads it: this workgroup is its only reader here.
+    uint2 range = a.ranges[tile];
+    {
+        const bool sort_bad = sort_err != nullptr && radix_failed(sort_err) != 0u;
+        if (sort_bad && tile == 0 && threadIdx.x == 0 && status) atomicOr(status, (uint32_t)MGS_STATUS_TILE_SORT_TIMEOUT);
+        if (sort_bad || range.x >= range.y) {
+            range = make_uint2(0u, 0u);
+            if (threadIdx.x == 0) ranges_rw[tile] = range;
+        }
+    }
 
     // T is the running transmittance.  Which pixels are still blending is a 64-bit lane mask kept in scalar registers
     // (`live`): every per-pixel decision below is a v_cmp that writes a lane mask, the masks are combined on the scalar
@@ -194,15 +205,19 @@ __global__ void __launch_bounds__(256) blend_forward_kernel(BlendArgs a, float* 
 
     uint32_t gid_n = 0;
     float4 box_n = make_float4(0.f, 0.f, -1.f, -1.f), ell_n = make_float4(0.f, 0.f, 0.f, 0.f);
-#ifdef MGS_FWD_LDSQ
-    // EXPERIMENT ("measured and rejected"): the whole 64-byte record of every instance of the next step is
-    // prefetched by its lane (the same cache line the cull data comes from) and parked in a per-wave LDS queue; a survivor's
-    // record then comes back with broadcast ds_reads instead of a dependent scalar-cache round trip per survivor.
+    // Round 4: the survivors' records come through a per-wave LDS queue instead of the scalar cache.  Every lane prefetches
+    // the WHOLE 64-byte record of its instance of the next step (the cache line its cull data comes from anyway: no extra
+    // line is touched) and parks {px, py, ex, ey | conic, opacity | colour, depth} in its queue entry; a survivor's record
+    // then comes back with three broadcast ds_reads of a wave-uniform address.  Against the scalar fetch this removes a
+    // dependent scalar-cache round trip per survivor (32 waves of different tiles share a 16 KB scalar cache: most of them
+    // went to L2) and five scalar instructions of address arithmetic: 0.215 -> 0.191 ms at C5, 38.0 -> 34.8 us at 100 k / VGA.
+    // (Rounds 2 built the same queue against the mask-algebra kernel and measured no gain: that kernel was bound by its
+    // scalar ALU work, not by the fetch.)  No barrier: the queue belongs to one wave and a wave's LDS operations run in order.
     __shared__ __attribute__((aligned(16))) float4 s_queue[4][WAVE][3];
     float4 c1_n = make_float4(0.f, 0.f, 0.f, 0.f), c2_n = c1_n;
     float4* const my_entry = &s_queue[wave][lane][0];
-    const uint32_t q_base = (uint32_t)(uintptr_t)&s_queue[wave][0][0];      // LDS byte address of this wave's queue
-#endif
+    // LDS byte address of this wave's queue, in a scalar register: an entry's address is then scalar arithmetic + one v_mov
+    const uint32_t q_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)&s_queue[threadIdx.x >> 6][0][0]);
     auto prefetch = [&](uint32_t i) {               // next step's index + cull data, issued one step ahead
         gid_n = 0;
         box_n = make_float4(0.f, 0.f, -1.f, -1.f);
@@ -210,10 +225,8 @@ __global__ void __launch_bounds__(256) blend_forward_kernel(BlendArgs a, float* 
             gid_n = a.point_list[i];
             box_n = a.rec[(size_t)gid_n * 4];
             ell_n = a.rec[(size_t)gid_n * 4 + 3];
-#ifdef MGS_FWD_LDSQ
             c1_n = a.rec[(size_t)gid_n * 4 + 1];
             c2_n = a.rec[(size_t)gid_n * 4 + 2];
-#endif
         }
     };
     auto walk_step = [&](auto touch_tag, uint32_t base, uint32_t gid_l, unsigned long long mask) {
@@ -223,7 +236,6 @@ __global__ void __launch_bounds__(256) blend_forward_kernel(BlendArgs a, float* 
         while (mask) {
             const int j = __builtin_ctzll(mask);
             mask &= ~(1ull << j);
-#ifdef MGS_FWD_LDSQ
             float4 e0, e1, e2;                      // uniform address: three broadcast reads
             {
                 const uint32_t ad = q_base + (uint32_t)j * 48u;
@@ -231,10 +243,6 @@ __global__ void __launch_bounds__(256) blend_forward_kernel(BlendArgs a, float* 
                              : "=&v"(*reinterpret_cast<float2*>(&e0)), "=&v"(e1), "=&v"(e2) : "v"(ad) : "memory");
             }
             const Rec g{e0.x, e0.y, e1.x, e1.y, e1.z, e1.w, e2.x, e2.y, e2.z, e2.w};
-#else
-            const uint32_t gid = bcast(gid_l, j);
-            const Rec g = fetch(a, gid);
-#endif
             const float dx = g.px - pxf, dy = g.py - pyf;
             const float power = dx * (g.ca * dx + g.cb * dy) + (g.cc * dy) * dy;     // log2 of the Gaussian falloff
             const float alpha = fminf(0.99f, g.op * __builtin_amdgcn_exp2f(power));
@@ -248,9 +256,7 @@ __global__ void __launch_bounds__(256) blend_forward_kernel(BlendArgs a, float* 
     for (uint32_t base = range.x; base < range.y && live != 0ull; base += WAVE) {
         const uint32_t gid_l = gid_n;
         const float4 c = box_n, el = ell_n;
-#ifdef MGS_FWD_LDSQ
         my_entry[0] = c; my_entry[1] = c1_n; my_entry[2] = c2_n;      // (the wave's own queue: LDS ops of a wave run in order)
-#endif
         prefetch(base + WAVE + lane);
         const unsigned long long mask = __builtin_amdgcn_ballot_w64(quadrant_hit(c, el, qx0, qy0, live));
         // a pixel counts as "touched" by an instance when T (1 - alpha) > 0.5: impossible once every live pixel has T <= 0.5
@@ -284,12 +290,12 @@ static BlendArgs make_args(const mgs_camera& cam, const GeometryState& g, const 
 
 int launch_blend_forward(const mgs_camera& cam, const GeometryState& g, const BinningState& b,
                          const ImageState& img, float* out_color, float* out_depth, float* out_opacity,
-                         int32_t* n_touched, hipStream_t s) {
+                         int32_t* n_touched, const uint32_t* sort_err, uint32_t* status, hipStream_t s) {
     const BlendArgs a = make_args(cam, g, b, img);
     const int ntiles = a.gx * tiles_y(a.H);
     if (ntiles == 0) return 0;
     hipLaunchKernelGGL(blend_forward_kernel, dim3(ntiles), dim3(256), 0, s, a, out_color, out_depth, out_opacity,
-                       img.final_T, img.n_contrib, n_touched);
+                       img.final_T, img.n_contrib, n_touched, img.ranges, sort_err, status);
     MGS_HIP(hipGetLastError());
     return 0;
 }
@@ -743,11 +749,7 @@ __global__ void __launch_bounds__(256) blend_backward_t_kernel(BlendArgs a, int 
             const bool act = (k_first + (uint32_t)j <= last) && !(power > 0.f) && !(alpha < 1.0f / 255.0f);
             if (__builtin_amdgcn_ballot_w64(act) == 0ull) return;
             const float a_eff = act ? alpha : 0.f;
-#ifdef MGS_EXP_IEEE_DIV
-            const float inv = 1.f / (1.f - a_eff);
-#else
-            const float inv = __builtin_amdgcn_rcpf(1.f - a_eff);
-#endif
+            const float inv = __builtin_amdgcn_rcpf(1.f - a_eff);    // (an IEEE divide changes no gradient digit: tools/grad_accuracy.py)
             const float Tn = T * inv;
             const float qq = __builtin_fmaf(g.z, gd, __builtin_fmaf(g.b, g2, __builtin_fmaf(g.g, g1, g.r * g0)));
             const float diff = qq - Bk;
@@ -768,16 +770,9 @@ __global__ void __launch_bounds__(256) blend_backward_t_kernel(BlendArgs a, int 
             const int j = 63 - __builtin_clzll(mask);
             mask &= ~(1ull << j);
             const Rec g = fetch(a, bcast(gid_l, j));
-#ifdef MGS_EXP_FETCH_ONCE
-            asm volatile("" ::"s"(g.r), "s"(g.g), "s"(g.b), "s"(g.z));      // the whole record in ONE scalar round trip
-#endif
             const float dx = g.px - pxf, dy = g.py - pyf;
             const float power = dx * (g.ca * dx + g.cb * dy) + (g.cc * dy) * dy;
-#ifdef MGS_EXP_PRECISE_EXP
-            const float G = exp2f(power);
-#else
             const float G = __builtin_amdgcn_exp2f(power);
-#endif
             apply(g, j, power, G, fminf(0.99f, g.op * G));
         }
     }

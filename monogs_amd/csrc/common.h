@@ -225,7 +225,9 @@ int radix_sort_pairs(uint32_t* ka, uint32_t* va, uint32_t* kb, uint32_t* vb, uin
                      const uint2* aux_in = nullptr, uint2* aux_out = nullptr,   // last pass also writes aux_out[i] = aux_in[value i]
                      const uint32_t* ext_hist = nullptr,
                      bool aux_empty_for_ones = false,        // a key of all ones gets aux (0, 0) without the fetch
-                     bool exclusive = false);                // MGS_FLAG_EXCLUSIVE_DEVICE: small sorts may use block ids as tile ids
+                     bool exclusive = false,                 // MGS_FLAG_EXCLUSIVE_DEVICE: small sorts may use block ids as tile ids
+                     uint2* ranges = nullptr);               // keys are small integers: ranges[key] = {first, last + 1} sorted position
+                                                             // (the final pass: atomicMin / atomicMax on words preset to {~0, 0})
 bool radix_wants_hist(uint64_t n);
 // The forward's first sort (radix_sort.hip): depth keys -> perm + rect_sorted; three 9-bit passes (+ a fourth that only
 // runs for depths beyond 13 107 units).  radix_depth_payload(n): the sort carries the packed rectangles itself.
@@ -237,14 +239,14 @@ int radix_sort_depth(uint32_t* keys, uint32_t* key_b, uint32_t* val_a, uint32_t*
 inline bool depth_sort_payload(int P, int W, int H) { return radix_depth_payload((uint64_t)P) && tiles_x(W) <= 255 && tiles_y(H) <= 255; }
 int launch_depth_sort(const GeometryState& g, int P, bool payload, hipStream_t s, bool exclusive = false);
 int launch_sort(const GeometryState& g, const BinningState& b, uint64_t R, int bits, hipStream_t s,
-                const uint32_t* n_dev = nullptr, bool exclusive = false);
-int launch_ranges(const BinningState& b, uint64_t R, const ImageState& img, int ntiles, int sort_bits, hipStream_t s,
-                  const uint32_t* n_dev = nullptr, uint32_t* status = nullptr);
+                const uint32_t* n_dev = nullptr, bool exclusive = false, uint2* ranges = nullptr);
 int set_radix_spin_limit(uint32_t limit);
 extern int g_opt_radix_ballot_rank, g_opt_radix_scanned, g_opt_knn_grid_min, g_opt_scan_small, g_opt_dup_slot_major, g_opt_blend_bwd_transposed;      // test knobs (mgs_debug_set_option)
+// `sort_err`: the tile sort's error words (NULL: nothing was sorted); a raised word empties every tile and sets
+// MGS_STATUS_TILE_SORT_TIMEOUT in *status (what ranges_kernel did until round 4)
 int launch_blend_forward(const mgs_camera& cam, const GeometryState& g, const BinningState& b,
                          const ImageState& img, float* out_color, float* out_depth, float* out_opacity,
-                         int32_t* n_touched, hipStream_t s);
+                         int32_t* n_touched, const uint32_t* sort_err, uint32_t* status, hipStream_t s);
 int launch_blend_backward(const mgs_camera& cam, const GeometryState& g, const BinningState& b,
                           const ImageState& img, const float* dL_dcolor, const float* dL_ddepth,
                           float* grad_acc, bool pose_only, hipStream_t s);

@@ -39,6 +39,11 @@ struct LossArgs {
 };
 
 __device__ __forceinline__ float sgn(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }
+// exp(a) * render + b - gt as PyTorch evaluates `torch.exp(a) * image + b` and the subtraction that follows
+// (/root/reference/utils/slam_utils.py:74,122): a multiply, an add, a subtract, each rounded on its own.  The SIGN of this
+// residual is the whole gradient of the L1 term, so a fused multiply-add here flips the pixels whose residual rounds to
+// zero one way and not the other (one element of 921 600 on the C2 frame: 1e-4 of relative L2 in dL/dmeans3D).
+__device__ __forceinline__ float residual(float ea, float x, float eb, float gt) { return __fsub_rn(__fadd_rn(__fmul_rn(ea, x), eb), gt); }
 
 // per-pixel terms of the forward sums (shared by the scalar and the 4-pixel paths)
 struct FwdAcc { float s_rgb, c_rgb, s_d, c_d, s_op, u_a, u_b; };
@@ -52,7 +57,7 @@ __device__ __forceinline__ void fwd_pixel(const LossArgs& a, float ea, float eb,
         m_d = m_d && opaque;
     }
     if (m_rgb) {
-        const float d0 = ea * r0 + eb - g0, d1 = ea * r1 + eb - g1, d2 = ea * r2 + eb - g2;
+        const float d0 = residual(ea, r0, eb, g0), d1 = residual(ea, r1, eb, g1), d2 = residual(ea, r2, eb, g2);
         acc.s_rgb += fabsf(d0) + fabsf(d1) + fabsf(d2);
         acc.c_rgb += 3.f;
         const float s0 = sgn(d0), s1 = sgn(d1), s2 = sgn(d2);
@@ -71,7 +76,7 @@ __device__ __forceinline__ void fwd_pixel(const LossArgs& a, float ea, float eb,
 template <bool VEC4>
 __global__ void __launch_bounds__(LS_THREADS) loss_forward_kernel(LossArgs a, float* __restrict__ part) {
     const size_t HW = (size_t)a.W * a.H;
-    const float ea = a.init ? 1.f : __expf(a.exp_a[0]), eb = a.init ? 0.f : a.exp_b[0];
+    const float ea = a.init ? 1.f : expf(a.exp_a[0]), eb = a.init ? 0.f : a.exp_b[0];      // (torch.exp: the accurate one)
     FwdAcc acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const size_t stride = (size_t)gridDim.x * LS_THREADS;
     if (VEC4) {
@@ -181,7 +186,7 @@ __global__ void __launch_bounds__(LS_THREADS) loss_backward_kernel(LossArgs a, f
     __shared__ float s_scale[2];
     const size_t HW = (size_t)a.W * a.H;
     const float go = grad_out ? grad_out[0] : 1.f;
-    const float ea = a.init ? 1.f : __expf(a.exp_a[0]), eb = a.init ? 0.f : a.exp_b[0];
+    const float ea = a.init ? 1.f : expf(a.exp_a[0]), eb = a.init ? 0.f : a.exp_b[0];      // (torch.exp: the accurate one)
     if (fwd_blocks > 0) {
         if (threadIdx.x < WAVE) {
             float v[LP_SUMS];
@@ -218,7 +223,7 @@ __global__ void __launch_bounds__(LS_THREADS) loss_backward_kernel(LossArgs a, f
         }
         o0 = o1 = o2 = 0.f;
         if (m_rgb) {
-            const float s0 = sgn(ea * x0 + eb - t0), s1 = sgn(ea * x1 + eb - t1), s2 = sgn(ea * x2 + eb - t2);
+            const float s0 = sgn(residual(ea, x0, eb, t0)), s1 = sgn(residual(ea, x1, eb, t1)), s2 = sgn(residual(ea, x2, eb, t2));
             o0 = k_rgb * ea * s0; o1 = k_rgb * ea * s1; o2 = k_rgb * ea * s2;
         }
         if (a.invert_depth) {                       // d/dd |1/(d + eps) - 1/(gd + eps)| = -sgn(.) / (d + eps)^2

@@ -414,6 +414,9 @@ struct RsPassArgs {
     int last;                 // cond 0: this pass is the final one
     int cond;                 // 0: plain; 1: final unless the wide flag is up (depth, third pass); 2: runs only if it is (fourth)
     const uint32_t* wide;
+    uint2* ranges;            // final pass of a sort whose keys are SMALL integers (tile ids): [key] receives {first, last + 1}
+                              // position of the key in the sorted order (min / max atomics on words preset to {~0, 0}): the
+                              // per-tile ranges of the rasteriser, which used to be a launch of their own (ranges_kernel)
     const uint32_t* counts;   // counted tiles: [tiles][radix] digit counts of every tile for this pass
     const uint32_t* sums;     // counted tiles: the levels >= 1 of the tree over them (RsTreeArgs)
     RsTreeArgs tree;
@@ -727,6 +730,20 @@ __global__ void __launch_bounds__(RS_THREADS, (SCANNED && ITEMS == RS_ITEMS_WIDE
         rank[i] = e < tile_n ? digit_base[d] + wave_hist[wv][d] + rank[i] : 0xFFFFFFFFu;      // slot inside the tile
     }
     rs_exchange<ITEMS>(sbuf, rank, key, t);
+    // Final pass with `ranges`: the staging buffer still holds the tile's keys in output order, and equal keys are neighbours
+    // there (same digit; the earlier passes ordered the rest).  An element whose left / right neighbour carries another key
+    // (or lies in another tile) opens / closes its key's run inside this tile.
+    uint32_t edge = 0;          // bit 2 i: element i opens a run, bit 2 i + 1: closes one
+    if (final_pass && a.ranges) {
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {
+            const uint32_t p = (uint32_t)i * RS_THREADS + t;
+            if (p < tile_n) {
+                if (p == 0 || sbuf[p - 1] != key[i]) edge |= 1u << (2 * i);
+                if (p + 1 == tile_n || sbuf[p + 1] != key[i]) edge |= 2u << (2 * i);
+            }
+        }
+    }
     __syncthreads();
     rs_exchange<ITEMS>(sbuf, rank, val, t);
     if constexpr (PAYLOAD) {
@@ -759,6 +776,13 @@ __global__ void __launch_bounds__(RS_THREADS, (SCANNED && ITEMS == RS_ITEMS_WIDE
             if (a.kfinal) a.kfinal[g[i]] = key[i];
             a.vfinal[g[i]] = val[i];
         }
+    if (a.ranges && edge) {     // a key's run may continue in the neighbouring tiles: every tile offers its piece's ends
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {
+            if (edge & (1u << (2 * i))) atomicMin(&a.ranges[key[i]].x, g[i]);
+            if (edge & (2u << (2 * i))) atomicMax(&a.ranges[key[i]].y, g[i] + 1u);
+        }
+    }
     RS_STAMP(5);
     RS_DRAIN();
     RS_STAMP(6);
@@ -850,6 +874,7 @@ static void rs_launch_pass_items(const RsPassArgs& a, int items, bool scanned, u
 }
 
 struct RsBuffers {
+    uint2* ranges;                 // see RsPassArgs::ranges (NULL: none)
     uint32_t *ka, *va, *pa;        // input (pa NULL: no payload)
     bool va_is_index;              // the first pass takes value = index instead of reading va (va is still written later)
     uint32_t *kb, *vb, *pb;        // ping-pong partners
@@ -909,6 +934,7 @@ static int rs_run(const RsPlan& pl, const RsBuffers& b, uint64_t n, void* temp, 
         // the final pass of a plain sort writes the ping-pong side; the depth sort has its own final arrays and no keys
         a.vfinal = b.vfinal ? b.vfinal : vout;
         a.kfinal = b.vfinal ? b.kfinal : kout;
+        a.ranges = (!pl.depth && p == pl.npasses - 1) ? b.ranges : nullptr;
         a.aux_in = b.aux_in; a.aux_out = b.aux_out; a.aux_skip_ones = b.aux_skip_ones ? 1 : 0;
         if (scanned) {
             RsTileHistArgs h;
@@ -940,10 +966,11 @@ static int rs_run(const RsPlan& pl, const RsBuffers& b, uint64_t n, void* temp, 
 
 int radix_sort_pairs(uint32_t* ka, uint32_t* va, uint32_t* kb, uint32_t* vb, uint64_t n, int bits, void* temp,
                      hipStream_t s, const uint32_t* n_dev, bool temp_zeroed, const uint2* aux_in, uint2* aux_out,
-                     const uint32_t* ext_hist, bool aux_empty_for_ones, bool exclusive) {
+                     const uint32_t* ext_hist, bool aux_empty_for_ones, bool exclusive, uint2* ranges) {
     const RsPlan pl = rs_plan_plain(bits);
     if (pl.npasses > RS_MAX_PASSES) { set_error("radix sort: more than 32 key bits"); return 1; }
     RsBuffers b;
+    b.ranges = ranges;
     b.ka = ka; b.va = va; b.va_is_index = false; b.pa = nullptr; b.kb = kb; b.vb = vb; b.pb = nullptr; b.kfinal = nullptr; b.vfinal = nullptr;
     b.aux_in = aux_in; b.aux_out = aux_out; b.aux_skip_ones = aux_empty_for_ones;
     return rs_run(pl, b, n, temp, s, n_dev, temp_zeroed, ext_hist, exclusive);
@@ -957,6 +984,7 @@ int radix_sort_depth(uint32_t* keys, uint32_t* key_b, uint32_t* val_a, uint32_t*
                      uint32_t* perm, uint2* rect_sorted, uint64_t n, void* temp, hipStream_t s, bool temp_zeroed, bool exclusive) {
     const RsPlan pl = rs_plan_for_depth(n);
     RsBuffers b;
+    b.ranges = nullptr;
     b.ka = keys; b.va = val_a; b.va_is_index = true; b.kb = key_b; b.vb = val_b;
     b.pa = payload ? (uint32_t*)rect : nullptr; b.pb = payload ? (uint32_t*)rect + n : nullptr;
     b.kfinal = nullptr; b.vfinal = perm;

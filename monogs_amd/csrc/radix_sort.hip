@@ -731,17 +731,16 @@ __global__ void __launch_bounds__(RS_THREADS, (SCANNED && ITEMS == RS_ITEMS_WIDE
     }
     rs_exchange<ITEMS>(sbuf, rank, key, t);
     // Final pass with `ranges`: the staging buffer still holds the tile's keys in output order, and equal keys are neighbours
-    // there (same digit; the earlier passes ordered the rest).  An element whose left / right neighbour carries another key
-    // (or lies in another tile) opens / closes its key's run inside this tile.
-    uint32_t edge = 0;          // bit 2 i: element i opens a run, bit 2 i + 1: closes one
+    // there (same digit; the earlier passes ordered the rest).  An element whose LEFT neighbour carries another key opens its
+    // key's run inside this tile -- and closes the neighbour's; the tile's first element opens, its last one closes.
+    uint32_t left[ITEMS];
+    uint32_t edge = 0;          // bit i: element i opens a run
     if (final_pass && a.ranges) {
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i) {
             const uint32_t p = (uint32_t)i * RS_THREADS + t;
-            if (p < tile_n) {
-                if (p == 0 || sbuf[p - 1] != key[i]) edge |= 1u << (2 * i);
-                if (p + 1 == tile_n || sbuf[p + 1] != key[i]) edge |= 2u << (2 * i);
-            }
+            left[i] = (p > 0 && p < tile_n) ? sbuf[p - 1] : 0xFFFFFFFFu;          // (no tile id is all ones)
+            if (p < tile_n && left[i] != key[i]) edge |= 1u << i;
         }
     }
     __syncthreads();
@@ -776,11 +775,16 @@ __global__ void __launch_bounds__(RS_THREADS, (SCANNED && ITEMS == RS_ITEMS_WIDE
             if (a.kfinal) a.kfinal[g[i]] = key[i];
             a.vfinal[g[i]] = val[i];
         }
-    if (a.ranges && edge) {     // a key's run may continue in the neighbouring tiles: every tile offers its piece's ends
+    if (final_pass && a.ranges) {     // a key's run may continue in other tiles: every tile offers the ends of its piece
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i) {
-            if (edge & (1u << (2 * i))) atomicMin(&a.ranges[key[i]].x, g[i]);
-            if (edge & (2u << (2 * i))) atomicMax(&a.ranges[key[i]].y, g[i] + 1u);
+            const uint32_t p = (uint32_t)i * RS_THREADS + t;
+            if (edge & (1u << i)) {
+                atomicMin(&a.ranges[key[i]].x, g[i]);
+                if (p > 0)          // the piece that ends at p - 1: its last position follows from ITS digit's base
+                    atomicMax(&a.ranges[left[i]].y, gbase[(rs_xf(left[i], a.sub) >> a.shift) & (RADIX - 1)] + p);
+            }
+            if (p + 1 == tile_n) atomicMax(&a.ranges[key[i]].y, g[i] + 1u);
         }
     }
     RS_STAMP(5);
@@ -935,6 +939,7 @@ static int rs_run(const RsPlan& pl, const RsBuffers& b, uint64_t n, void* temp, 
         a.vfinal = b.vfinal ? b.vfinal : vout;
         a.kfinal = b.vfinal ? b.kfinal : kout;
         a.ranges = (!pl.depth && p == pl.npasses - 1) ? b.ranges : nullptr;
+        if (a.ranges) a.kfinal = nullptr;       // whoever asks for the ranges does not read the sorted keys: 4 n bytes of stores less
         a.aux_in = b.aux_in; a.aux_out = b.aux_out; a.aux_skip_ones = b.aux_skip_ones ? 1 : 0;
         if (scanned) {
             RsTileHistArgs h;

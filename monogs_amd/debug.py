@@ -70,7 +70,10 @@ def forward_tables(rs, means3D, opacities, colors_precomp=None, shs=None, scales
     # binning scratch: keys_a, keys_b, vals_a, vals_b; an LSD pass per 8 key bits ping-pongs a -> b -> a ...
     tile_bits = max(1, (ntiles - 1).bit_length())
     in_b = ((tile_bits + 7) // 8) % 2 == 1
-    tile_sorted = view(binning, _au(r * 4) if in_b else 0, R * 4, torch.int32)      # tile id per instance, grouped
+    # tile id per sorted instance.  Since round 4 the tile sort's final pass writes the per-tile ranges instead of the sorted
+    # keys (nobody reads them): the tile of instance i is the tile whose range holds i.
+    rg = ranges.long()
+    tile_sorted = torch.repeat_interleave(torch.arange(ntiles, device=ranges.device), (rg[:, 1] - rg[:, 0]).clamp_min(0)).to(torch.int32)
     point_list = view(binning, (3 if in_b else 2) * _au(r * 4), R * 4, torch.int32)
     rec = view(geom, 0, P * 64, torch.float32).reshape(P, 16)
     o = _au(P * 64)

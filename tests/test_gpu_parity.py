@@ -308,7 +308,15 @@ def test_c5_full_size_properties(native_lib, monkeypatch):
     assert bool((d >= 0).all())
     same = d == 0
     assert bool((pl[1:][same] > pl[:-1][same]).all())
-    # every instance sits in the tile its range says
+    # every instance sits in a tile its Gaussian's rectangle covers (the sorted tile ids are no longer materialised: `tile`
+    # is derived from the ranges, so this checks ranges + blend order against the per-Gaussian geometry)
+    gx, gy = (st.image_width + 15) // 16, (st.image_height + 15) // 16
+    rec = t["rec"][pl]
+    cl = lambda v, hi: v.clamp(0, hi)  # noqa: E731
+    x0, x1 = cl(torch.trunc((rec[:, 0] - rec[:, 15]) / 16), gx), cl(torch.trunc((rec[:, 0] + rec[:, 15] + 15) / 16), gx)
+    y0, y1 = cl(torch.trunc((rec[:, 1] - rec[:, 15]) / 16), gy), cl(torch.trunc((rec[:, 1] + rec[:, 15] + 15) / 16), gy)
+    tx, ty = (tile % gx).float(), (tile // gx).float()
+    assert bool(((tx >= x0) & (tx < x1) & (ty >= y0) & (ty < y1)).all())
     starts = torch.repeat_interleave(torch.arange(rg.shape[0], device=DEV), (rg[:, 1] - rg[:, 0]))
     assert torch.equal(starts, tile)
     # image invariants

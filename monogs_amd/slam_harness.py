@@ -353,8 +353,10 @@ def eager_tracking_probe(frames, intr, gmap, bg, iters: int):
                           syncs), the pose step ``torch.optim.Adam`` + ``update_pose`` in torch ops (a host read-back each);
     ``fused_losses``      + ``monogs_amd.fused_losses.get_loss_tracking`` (same signature, two launches);
     ``fused_pose_step``   + ``PoseAdam.step_and_retract`` (Adam + retraction + camera tensors in one launch);
-    ``render_loss_backward`` the part this repository owns, alone: render + fused loss + backward, no pose step (what
-                          tools/host_overhead.py times), with the device span of the same iterations beside it.
+    ``render_loss_backward`` render + fused loss + backward, no pose step, with the device span of the same iterations;
+    ``seam_only``         the same through the drop-in seam ALONE: the five map tensors handed over as already-activated
+                          leaves, so that autograd stops at the rasteriser (no normalize / exp / sigmoid kernels and their
+                          backward: those belong to the caller's GaussianModel getters) -- what tools/host_overhead.py times.
     Fixed iteration count (no early exit), pose and exposure restored afterwards."""
     from . import rasterizer as _r
     was = _r.sync_free_enabled()
@@ -374,7 +376,11 @@ def eager_tracking_probe(frames, intr, gmap, bg, iters: int):
         for p in gmap.params():
             p.grad = None
     try:
-        for name in ("torch_losses", "fused_losses", "fused_pose_step", "render_loss_backward"):
+        leaves = None
+        for name in ("torch_losses", "fused_losses", "fused_pose_step", "render_loss_backward", "seam_only"):
+            if name == "seam_only":
+                with torch.no_grad():
+                    leaves = [t.detach().clone().requires_grad_(True) for t in map_tensors()]
             loss_fn = reference_style_tracking_loss if name == "torch_losses" else fused_losses.get_loss_tracking
             if name in ("torch_losses", "fused_losses"):
                 opt = torch.optim.Adam([dict(params=[vp.cam_rot_delta], lr=0.003), dict(params=[vp.cam_trans_delta], lr=0.001),
@@ -386,9 +392,12 @@ def eager_tracking_probe(frames, intr, gmap, bg, iters: int):
 
             def it():
                 zero()
-                pkg = render(vp, intr, *map_tensors(), bg)
+                pkg = render(vp, intr, *(leaves if leaves is not None else map_tensors()), bg)
                 loss = loss_fn(pkg["render"], pkg["depth"], pkg["opacity"], vp)
                 loss.backward()
+                if leaves is not None:
+                    for t in leaves:
+                        t.grad = None
                 with torch.no_grad():
                     if name in ("torch_losses", "fused_losses"):
                         opt.step()
@@ -414,8 +423,10 @@ def eager_tracking_probe(frames, intr, gmap, bg, iters: int):
 
         def it_dev():
             popt.zero_grad()
-            pkg = render(vp, intr, *map_tensors(), bg)
+            pkg = render(vp, intr, *leaves, bg)
             fused_losses.get_loss_tracking(pkg["render"], pkg["depth"], pkg["opacity"], vp).backward()
+            for t in leaves:
+                t.grad = None
         for _ in range(10):
             it_dev()
         torch.cuda.synchronize()
@@ -425,7 +436,7 @@ def eager_tracking_probe(frames, intr, gmap, bg, iters: int):
             it_dev()
         e1.record()
         torch.cuda.synchronize()
-        out["render_loss_backward"]["device_ms_per_iter"] = round(e0.elapsed_time(e1) / iters, 4)
+        out["seam_only"]["device_ms_per_iter"] = round(e0.elapsed_time(e1) / iters, 4)
         _r.check_overflow()
         restore()
     finally:

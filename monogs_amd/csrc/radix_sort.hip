@@ -730,19 +730,6 @@ __global__ void __launch_bounds__(RS_THREADS, (SCANNED && ITEMS == RS_ITEMS_WIDE
         rank[i] = e < tile_n ? digit_base[d] + wave_hist[wv][d] + rank[i] : 0xFFFFFFFFu;      // slot inside the tile
     }
     rs_exchange<ITEMS>(sbuf, rank, key, t);
-    // Final pass with `ranges`: the staging buffer still holds the tile's keys in output order, and equal keys are neighbours
-    // there (same digit; the earlier passes ordered the rest).  An element whose LEFT neighbour carries another key opens its
-    // key's run inside this tile -- and closes the neighbour's; the tile's first element opens, its last one closes.
-    uint32_t left[ITEMS];
-    uint32_t edge = 0;          // bit i: element i opens a run
-    if (final_pass && a.ranges) {
-#pragma unroll
-        for (int i = 0; i < ITEMS; ++i) {
-            const uint32_t p = (uint32_t)i * RS_THREADS + t;
-            left[i] = (p > 0 && p < tile_n) ? sbuf[p - 1] : 0xFFFFFFFFu;          // (no tile id is all ones)
-            if (p < tile_n && left[i] != key[i]) edge |= 1u << i;
-        }
-    }
     __syncthreads();
     rs_exchange<ITEMS>(sbuf, rank, val, t);
     if constexpr (PAYLOAD) {
@@ -775,14 +762,30 @@ __global__ void __launch_bounds__(RS_THREADS, (SCANNED && ITEMS == RS_ITEMS_WIDE
             if (a.kfinal) a.kfinal[g[i]] = key[i];
             a.vfinal[g[i]] = val[i];
         }
-    if (final_pass && a.ranges) {     // a key's run may continue in other tiles: every tile offers the ends of its piece
+    if (a.ranges) {
+        // The per-key ranges (the rasteriser's tile ranges), from the keys this thread holds in output order: equal keys are
+        // neighbours in the tile's digit-ordered array (same digit; the earlier passes ordered the rest), so an element whose
+        // LEFT neighbour carries another key opens its key's run inside this tile and closes the neighbour's; the tile's
+        // first element opens, its last one closes.  A key's run may continue in other tiles: every tile offers the ends of
+        // its piece (atomicMin / atomicMax on words preset to {~0, 0}).  The left neighbour of element (i, t) is element
+        // (i, t - 1): the lane below, or -- lane 0 -- the previous wave's last lane, handed over through 4 x ITEMS words of
+        // LDS.  (Done here, after the stores, on registers that are live anyway: kept across the exchanges the neighbour keys
+        // cost 30 spilled VGPRs in the 72-register kernel of the C5 tile sort.)
+        __shared__ uint32_t s_edge[RS_WAVES * ITEMS];
+        if (lane == 63) {
+#pragma unroll
+            for (int i = 0; i < ITEMS; ++i) s_edge[wv * ITEMS + i] = key[i];
+        }
+        __syncthreads();
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i) {
             const uint32_t p = (uint32_t)i * RS_THREADS + t;
-            if (edge & (1u << i)) {
+            uint32_t l = (uint32_t)__shfl_up((int)key[i], 1, 64);
+            if (lane == 0) l = wv > 0 ? s_edge[(wv - 1) * ITEMS + i] : (i > 0 ? s_edge[(RS_WAVES - 1) * ITEMS + i - 1] : 0xFFFFFFFFu);
+            if (p < tile_n && (p == 0 || l != key[i])) {
                 atomicMin(&a.ranges[key[i]].x, g[i]);
                 if (p > 0)          // the piece that ends at p - 1: its last position follows from ITS digit's base
-                    atomicMax(&a.ranges[left[i]].y, gbase[(rs_xf(left[i], a.sub) >> a.shift) & (RADIX - 1)] + p);
+                    atomicMax(&a.ranges[l].y, gbase[(rs_xf(l, a.sub) >> a.shift) & (RADIX - 1)] + p);
             }
             if (p + 1 == tile_n) atomicMax(&a.ranges[key[i]].y, g[i] + 1u);
         }

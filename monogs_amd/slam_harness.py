@@ -344,7 +344,7 @@ def reference_style_tracking_loss(render_image, render_depth, render_opacity, vi
     return 0.5 * l1_rgb + l1_depth
 
 
-def eager_tracking_probe(frames, intr, gmap, bg, iters: int):
+def eager_tracking_probe(frames, intr, gmap, bg, iters: int, profile_flavour=None):
     """The rate an UNMODIFIED MonoGS tracker gets from the drop-in: the loop of /root/reference/utils/slam_tracker.py:138-176
     -- ``render()`` through the seam (exact instance count: one read-back per forward, as upstream), the map's tensors
     requiring grad as the tracker's copy of the Gaussians does, ``loss.backward()``, ``torch.optim.Adam`` on the four pose /
@@ -358,7 +358,9 @@ def eager_tracking_probe(frames, intr, gmap, bg, iters: int):
                           leaves, so that autograd stops at the rasteriser (no normalize / exp / sigmoid kernels and their
                           backward: those belong to the caller's GaussianModel getters) -- what tools/host_overhead.py times.
     Fixed iteration count (no early exit), pose and exposure restored afterwards."""
+    import os
     from . import rasterizer as _r
+    profile_flavour = profile_flavour or os.environ.get("MGS_PROBE_PROFILE")
     was = _r.sync_free_enabled()
     _r.set_sync_free(False)
     vp = frames[-1]
@@ -416,6 +418,17 @@ def eager_tracking_probe(frames, intr, gmap, bg, iters: int):
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
             out[name] = dict(iters=iters, ms_per_iter=round(1e3 * dt / iters, 4), iters_per_s=round(iters / dt, 1))
+            if profile_flavour == name:        # where the host time of this flavour goes (diagnostic)
+                import cProfile
+                import pstats
+                import sys
+                pr = cProfile.Profile()
+                pr.enable()
+                for _ in range(iters):
+                    it()
+                torch.cuda.synchronize()
+                pr.disable()
+                pstats.Stats(pr, stream=sys.stderr).sort_stats("tottime").print_stats(18)
             restore()
         # device time of render + loss + backward alone: the same iteration with the host queued ahead (capacity mode)
         _r.set_sync_free(True)
@@ -437,6 +450,16 @@ def eager_tracking_probe(frames, intr, gmap, bg, iters: int):
         e1.record()
         torch.cuda.synchronize()
         out["seam_only"]["device_ms_per_iter"] = round(e0.elapsed_time(e1) / iters, 4)
+        _r.set_sync_free(False)
+        with _r.collect_timing() as sink:          # one exact iteration with HIP events between the stages: what the device does
+            it_dev()
+            torch.cuda.synchronize()
+        st = {}
+        for d in sink:
+            st.update({k: round(v, 4) for k, v in d.items() if k.endswith("_ms") and v > 0})
+            if d.get("kind") == "forward":
+                out["seam_only"]["num_rendered"] = int(d["num_rendered"])
+        out["seam_only"]["stages_ms"] = st
         _r.check_overflow()
         restore()
     finally:
@@ -601,6 +624,13 @@ def run_slam(n_frames=12, intrinsics="fr3_office", tracking_itr_num=100, mapping
         covisibility_pruned=sum(n for _, n in mapper.coviz_log),
         gaussians_after_keyframe=[n for _, n in size_trace], log=sl[:6] + sl[-4:] if len(sl) > 10 else sl)
     if eager_probe:
+        # (the captured graphs of the run and their private pools go first: the probe measures an eager caller, not one that
+        #  shares its process with a few dozen instantiated hipGraphs)
+        import gc
+        mapper._drop_plan()
+        mapper._pool = None
+        gc.collect()
+        torch.cuda.empty_cache()
         out["eager_tracking"] = eager_tracking_probe(frames, intr, gmap, bg, int(eager_probe))
     out.update(frames=n_frames, gaussians=int(gmap.get_xyz.shape[0]), width=intr.width, height=intr.height,
                tracking_fps=stats["tracked"] / max(stats["track_s"], 1e-9),

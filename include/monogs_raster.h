@@ -81,7 +81,7 @@ typedef struct mgs_timing {
     float scan_ms;
     float duplicate_ms;
     float sort_ms;
-    float ranges_ms;
+    float ranges_ms;      /* always 0 since ABI v8: the tile sort's final pass writes the ranges (kept for layout compatibility) */
     float blend_fwd_ms;
     float blend_bwd_ms;
     float geom_bwd_ms;

@@ -242,7 +242,6 @@ static int forward_render_impl(const mgs_camera* cam, int32_t P, uint64_t R, boo
     // (the sort's final pass writes the per-tile ranges: no ranges launch since round 4)
     if (int rc = launch_sort(g, b, R, tile_bits(W, H), s, n_dev, (cam->flags & MGS_FLAG_EXCLUSIVE_DEVICE) != 0, img.ranges)) return rc;
     tm.mark();
-    tm.mark();
     if (int rc = launch_blend_forward(*cam, g, b, img, out_color, out_depth, out_opacity, n_touched,
                                       R > 0 ? radix_error_flag(b.sort_temp, R, tile_bits(W, H)) : nullptr, overflow, s)) return rc;
     tm.mark();
@@ -250,8 +249,8 @@ static int forward_render_impl(const mgs_camera* cam, int32_t P, uint64_t R, boo
         tm.sync();
         timing->duplicate_ms = tm.ms(0);
         timing->sort_ms = tm.ms(1);
-        timing->ranges_ms = tm.ms(2);
-        timing->blend_fwd_ms = tm.ms(3);
+        timing->ranges_ms = 0.f;              // (no ranges launch since round 4: the tile sort's final pass writes them)
+        timing->blend_fwd_ms = tm.ms(2);
     }
     return 0;
 }

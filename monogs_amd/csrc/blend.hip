@@ -725,14 +725,6 @@ __global__ void __launch_bounds__(256) blend_backward_t_kernel(BlendArgs a, int 
 
     uint32_t gid_n = 0;
     float4 box_n = make_float4(0.f, 0.f, -1.f, -1.f), ell_n = make_float4(0.f, 0.f, 0.f, 0.f);
-#ifdef MGS_BWD_LDSQ
-    // EXPERIMENT: the forward's record queue in the backward (12 KB more LDS: six workgroups per CU instead of eight, and the
-    // record in vector registers)
-    __shared__ __attribute__((aligned(16))) float4 s_queue[4][WAVE][3];
-    float4 c1_n = make_float4(0.f, 0.f, 0.f, 0.f), c2_n = c1_n;
-    float4* const my_entry = &s_queue[wave][lane][0];
-    const uint32_t q_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)&s_queue[threadIdx.x >> 6][0][0]);
-#endif
     auto prefetch = [&](int b) {
         gid_n = 0;
         box_n = make_float4(0.f, 0.f, -1.f, -1.f);
@@ -741,19 +733,12 @@ __global__ void __launch_bounds__(256) blend_backward_t_kernel(BlendArgs a, int 
             gid_n = a.point_list[i];
             box_n = a.rec[(size_t)gid_n * 4];
             ell_n = a.rec[(size_t)gid_n * 4 + 3];
-#ifdef MGS_BWD_LDSQ
-            c1_n = a.rec[(size_t)gid_n * 4 + 1];
-            c2_n = a.rec[(size_t)gid_n * 4 + 2];
-#endif
         }
     };
     prefetch((int)((maxc - 1) / WAVE));
     for (int b = (int)((maxc - 1) / WAVE); b >= 0; --b) {
         const uint32_t gid_l = gid_n;
         const float4 c = box_n, el = ell_n;
-#ifdef MGS_BWD_LDSQ
-        my_entry[0] = c; my_entry[1] = c1_n; my_entry[2] = c2_n;
-#endif
         prefetch(b - 1);
         const unsigned long long alive = __builtin_amdgcn_ballot_w64(last >= (uint32_t)b * WAVE + 1u);
         unsigned long long mask = __builtin_amdgcn_ballot_w64(quadrant_hit(c, el, qx0, qy0, alive));
@@ -784,17 +769,7 @@ __global__ void __launch_bounds__(256) blend_backward_t_kernel(BlendArgs a, int 
         while (mask) {
             const int j = 63 - __builtin_clzll(mask);
             mask &= ~(1ull << j);
-#ifdef MGS_BWD_LDSQ
-            float4 e0, e1, e2;
-            {
-                const uint32_t ad = q_base + (uint32_t)j * 48u;
-                asm volatile("ds_read_b64 %0, %3\n\tds_read_b128 %1, %3 offset:16\n\tds_read_b128 %2, %3 offset:32\n\ts_waitcnt lgkmcnt(0)"
-                             : "=&v"(*reinterpret_cast<float2*>(&e0)), "=&v"(e1), "=&v"(e2) : "v"(ad) : "memory");
-            }
-            const Rec g{e0.x, e0.y, e1.x, e1.y, e1.z, e1.w, e2.x, e2.y, e2.z, e2.w};
-#else
             const Rec g = fetch(a, bcast(gid_l, j));
-#endif
             const float dx = g.px - pxf, dy = g.py - pyf;
             const float power = dx * (g.ca * dx + g.cb * dy) + (g.cc * dy) * dy;
             const float G = __builtin_amdgcn_exp2f(power);

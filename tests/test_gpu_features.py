@@ -455,6 +455,66 @@ def test_tile_sort_timeout_raises_its_own_status_bit_and_blends_nothing(native_l
     assert int(bad["ranges"].abs().max()) == 0
 
 
+@pytest.mark.parametrize("n,intr", [(3000, "fr3_office"), (60000, "fr3_office"), (40000, "replica")])
+def test_ticket_and_block_id_tile_ids_agree(native_lib, n, intr):
+    """Every one-sweep radix pass hands out its tile ids by an atomic ticket (placement-independent forward progress beside
+    other grids); a caller that declares the device its own (`MGS_FLAG_EXCLUSIVE_DEVICE`, `rasterizer.exclusive_device()`)
+    gets block ids for sorts of at most 256 tiles.  Same tables, same image, bit for bit, exact and capacity mode."""
+    from monogs_amd import rasterizer as R
+    from monogs_amd.debug import forward_tables
+    from monogs_amd.rasterizer import GaussianRasterizer
+    sc = make_scene(n, intr, seed=21)
+    st = _hip_st(sc)
+    dev = lambda t: t.to(DEV)  # noqa: E731
+    args = dict(colors_precomp=dev(sc.colors), scales=dev(sc.scales), rotations=dev(sc.rotations))
+    full = dict(means3D=dev(sc.means3D), means2D=torch.zeros(n, 3, device=DEV), opacities=dev(sc.opacities), **args)
+    out = {}
+    try:
+        for excl in (False, True):
+            with R.exclusive_device(excl):
+                out[excl] = forward_tables(st, dev(sc.means3D), dev(sc.opacities), **args)
+                R.set_sync_free(True)
+                with torch.no_grad():
+                    out[excl]["cap"] = GaussianRasterizer(st)(**full)[0]
+                assert not R.check_overflow()
+                R.set_sync_free(False)
+    finally:
+        R.set_sync_free(False)
+    assert out[False]["num_rendered"] == out[True]["num_rendered"] > 0 and out[False]["status"] == out[True]["status"] == 0
+    for k in ("ranges", "point_list", "perm", "color", "n_contrib", "n_touched"):
+        assert torch.equal(out[False][k], out[True][k]), k
+    assert torch.equal(out[False]["cap"], out[True]["cap"]) and torch.equal(out[False]["cap"], out[False]["color"])
+
+
+def test_exact_status_words_of_other_streams_wait_for_check_overflow(native_lib):
+    """The exact path hands the previous forward's status word to the next forward's count read-back only when both ran on the
+    same stream of the same device (the read-back is ordered behind that stream's kernels only); a word written on another
+    stream is parked and read by check_overflow(), which drains the devices involved first."""
+    from monogs_amd import rasterizer as R
+    from monogs_amd.rasterizer import GaussianRasterizer
+    sc = make_scene(4000, "fr3_office", seed=5)
+    st = _hip_st(sc)
+    dev = lambda t: t.to(DEV)  # noqa: E731
+    args = dict(means3D=dev(sc.means3D), means2D=torch.zeros(4000, 3, device=DEV), opacities=dev(sc.opacities),
+                colors_precomp=dev(sc.colors), scales=dev(sc.scales), rotations=dev(sc.rotations))
+    R.check_overflow()
+    R.set_sync_free(False)
+    side = torch.cuda.Stream()
+    with torch.no_grad():
+        a = GaussianRasterizer(st)(**args)                       # current stream: its word is pending
+        assert R._State.exact_pending is not None and not R._State.exact_other
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            b = GaussianRasterizer(st)(**args)                   # another stream: the first word is parked, not read
+        assert len(R._State.exact_other) == 1 and R._State.exact_pending is not None
+        side.synchronize()
+        c = GaussianRasterizer(st)(**args)                       # back on the first stream: the side stream's word is parked too
+        assert len(R._State.exact_other) == 2
+    assert not R.check_overflow()                                # reads all three after draining the device
+    assert R._State.exact_pending is None and not R._State.exact_other
+    assert torch.equal(a[0], b[0]) and torch.equal(a[0], c[0])
+
+
 def test_streams_nograd_and_noncontiguous_inputs(native_lib):
     """The library launches on the caller's current stream, works under no_grad, with inputs that do not
     require grad and with non-contiguous views (made contiguous at the boundary, as upstream's .contiguous())."""

@@ -52,6 +52,9 @@ def parse():
                     help="c5: one 1080p keyframe per GPU (headline); c4: 8-keyframe Replica mapping window sharded over the GPUs")
     ap.add_argument("--window", type=int, default=8, help="c4: keyframes in the mapping window")
     ap.add_argument("--eager", action="store_true", help="c4: no hipGraph replay (every iteration launched from Python)")
+    ap.add_argument("--exchange", choices=("bucket", "per_keyframe"), default="bucket",
+                    help="c4, N > 1: one all-reduce of the summed gradient bucket per iteration (default), or one per owned keyframe "
+                         "issued behind its backward while the next keyframe renders (WindowMapper.exchange)")
     args = ap.parse_args()
     if args.steps is None:
         args.steps = 6000 if args.workload == "c5" else 200
@@ -158,6 +161,7 @@ def bench_c4(args, rank, world, dev, distributed, rehearsal):
         vp.update_RT(vp.R_gt.clone(), vp.T_gt.clone())
     mapper = WindowMapper(gmap, intr, bg, window_size=args.window, use_graph=not args.eager)
     mapper.map_surgery = False                   # fixed workload: no densification / opacity reset inside the timed region
+    mapper.exchange = args.exchange
     P, H, W = len(gmap), intr.height, intr.width
 
     def fence():
@@ -207,7 +211,7 @@ def bench_c4(args, rank, world, dev, distributed, rehearsal):
             "config": {"workload": f"C4: mapping iteration over a {args.window}-keyframe window, {W}x{H} (Replica intrinsics), "
                                    f"{P} Gaussians, keyframes sharded k % {world}; per keyframe render (screen-space holder, radii, "
                                    f"n_touched) + get_loss_mapping + backward; per-keyframe densification statistics + MAX radii + "
-                                   f"visibility bits; all-reduce + all-gather; fused Adam + xyz lr schedule + pose steps; "
+                                   f"visibility bits; all-reduce ({args.exchange}) + all-gather; fused Adam + xyz lr schedule + pose steps; "
                                    + ("eager" if args.eager else "hipGraph-replayed")
                                    + (" [REHEARSAL: ranks share a device, gloo]" if rehearsal else ""),
                        "gaussians": P, "width": W, "height": H, "window": args.window,

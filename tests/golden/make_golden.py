@@ -11,6 +11,7 @@ Outputs (data only -- inputs and the reference's outputs):
   losses_invert.npz: the same with invert_depth=True
   lr_schedule.npz : general_utils.helper (the xyz learning-rate schedule of update_learning_rate)
   median_depth.npz: get_median_depth (value, std, valid mask) on a seeded depth image with holes, with and without a mask
+  grad_mask.npz   : image_gradient / image_gradient_mask combined as compute_grad_mask does (the tracking loss's edge mask)
 """
 import math
 import os
@@ -192,9 +193,49 @@ def lr_schedule():
     np.savez_compressed(os.path.join(HERE, "lr_schedule.npz"), **out)
 
 
+def grad_mask():
+    """The tracking loss's edge mask: ``image_gradient`` / ``image_gradient_mask`` (/root/reference/utils/slam_utils.py:6-40)
+    run as they are, combined as ``CameraExtrinsics.compute_grad_mask`` combines them (utils/camera_utils.py:185-216; that
+    method needs a dataset object, its eight lines of tensor arithmetic are repeated here around the reference's two functions).
+    Both functions create their filter taps with ``device="cuda"``; there is no GPU in this container, so for the duration of
+    the calls the module's ``torch.tensor`` / ``torch.ones`` are wrapped to drop that one keyword -- placement only, the
+    convolutions, paddings and comparisons that produce the values are the reference's own."""
+    import utils.slam_utils as su
+
+    class _CpuTorch:
+        def __getattr__(self, name):
+            f = getattr(torch, name)
+            if name in ("tensor", "ones"):
+                return lambda *a, **k: f(*a, **{kk: vv for kk, vv in k.items() if kk != "device"})
+            return f
+    g = torch.Generator().manual_seed(404)
+    imgs = []
+    # a smooth image with edges, one with a black border / black patches (the 3x3 validity mask matters), plain noise
+    yy, xx = torch.meshgrid(torch.arange(60.0), torch.arange(80.0), indexing="ij")
+    a = torch.stack([0.5 + 0.4 * torch.sin(xx / 7.0) * torch.cos(yy / 5.0), 0.5 + 0.3 * torch.tanh((xx - 40) / 2.0) * 0.9,
+                     0.3 + 0.6 * ((xx // 10 + yy // 10) % 2)]).clamp(0, 1)
+    b = a.clone(); b[:, :6] = 0; b[:, :, -9:] = 0; b[:, 30:40, 20:33] = 0
+    c = torch.rand(3, 60, 80, generator=g)
+    imgs = [a, b, c]
+    out = {"images": torch.stack(imgs).numpy()}
+    real = su.torch
+    su.torch = _CpuTorch()
+    try:
+        for i, rgb in enumerate(imgs):
+            gray = rgb.mean(dim=0, keepdim=True)
+            gv, gh = su.image_gradient(gray)
+            mv, mh = su.image_gradient_mask(gray)
+            inten = torch.sqrt((gv * mv) ** 2 + (gh * mh) ** 2)
+            out[f"intensity_{i}"] = inten.numpy()
+            out[f"mask_{i}"] = (inten > inten.median() * 1.1).numpy()        # edge_threshold = 1.1 (camera_utils.py:186)
+    finally:
+        su.torch = real
+    np.savez_compressed(os.path.join(HERE, "grad_mask.npz"), **out)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] in ("median_depth", "lr_schedule", "losses_invert"):   # add one fixture without rewriting the others
-        {"median_depth": median_depth, "lr_schedule": lr_schedule, "losses_invert": losses_invert}[sys.argv[1]]()
+    if len(sys.argv) > 1 and sys.argv[1] in ("median_depth", "lr_schedule", "losses_invert", "grad_mask"):   # add one fixture without rewriting the others
+        {"median_depth": median_depth, "lr_schedule": lr_schedule, "losses_invert": losses_invert, "grad_mask": grad_mask}[sys.argv[1]]()
         sys.exit(0)
     camera_pose()
     sh_eval()
@@ -202,4 +243,5 @@ if __name__ == "__main__":
     losses_invert()
     median_depth()
     lr_schedule()
+    grad_mask()
     print("golden fixtures written to", HERE)

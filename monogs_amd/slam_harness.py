@@ -2,19 +2,23 @@
 (tracking / mapping FPS, BASELINE.json configs 3-4) without the reference's control plane.
 
 This is measurement scaffolding on the CALLER's side of the boundary, not a re-implementation of
-MonoGS: no processes, queues, viewer, dataset parsers, densify/prune.  It reproduces the two hot
-loops that drive the rasteriser exactly as the reference does:
+MonoGS: no viewer, dataset parsers, keyframe selection by overlap (``run_slam_two_process`` has the
+reference's tracker / mapper process split).  It reproduces the two hot loops that drive the rasteriser
+exactly as the reference does:
 
 * tracking  (/root/reference/utils/slam_tracker.py:83-193): pose-only Adam (rot 0.003, trans 0.001,
   exposure 0.01 -- /root/reference/configs/mono/tum/base_config.yaml:46-48), <= ``tracking_itr_num``
   iterations of render -> get_loss_tracking -> backward -> step -> update_pose, early exit when the
   retraction step is < 1e-4;
-* mapping   (/root/reference/utils/slam_mapper.py:244-500): per iteration render every window keyframe,
-  sum get_loss_mapping, ONE backward, Adam step on the Gaussians and on the window poses.
+* mapping   (/root/reference/utils/slam_mapper.py:169-242,244-500) through ``monogs_amd.mapping.WindowMapper``: per
+  iteration render every window keyframe, sum get_loss_mapping, ONE backward, statistics, Adam step on the Gaussians and
+  on the window poses; with ``map_surgery`` the reference's densify_and_prune / opacity resets / covisibility pruning on
+  its own schedule.
 
 The camera objects are duck-typed stand-ins for the reference's CameraIntrinsics / CameraExtrinsics
-(/root/reference/utils/camera_utils.py:8-79,82-221).  Frames come from a seeded ground-truth map
-rendered by the same rasteriser (the datasets of configs 3-4 are not available offline).
+(/root/reference/utils/camera_utils.py:8-79,82-221).  The datasets of configs 3-4 are not available offline; frames come
+from an opaque box room ray-cast analytically (``make_room_sequence``: what bench.py runs, survives the reference's
+pruning) or, historically, from a seeded cloud of Gaussians rendered by the same rasteriser (``make_sequence``).
 """
 from __future__ import annotations
 

@@ -48,6 +48,9 @@ def parse():
                     help="steps timed per stage with HIP events, outside the timed region (median reported; an event\n"
                          "between every two stages costs a few us of stream time each, so the stages add up to a few\n"
                          "percent MORE than ms_per_step)")
+    ap.add_argument("--trace-steps", type=int, default=0,
+                    help="diagnostic: after the timed region, N more steps behind a fence with a HIP event after each one; prints "
+                         "the per-step device time (how long a short run takes to reach the steady state)")
     ap.add_argument("--workload", choices=("c5", "c4"), default="c5",
                     help="c5: one 1080p keyframe per GPU (headline); c4: 8-keyframe Replica mapping window sharded over the GPUs")
     ap.add_argument("--window", type=int, default=8, help="c4: keyframes in the mapping window")
@@ -329,6 +332,18 @@ def main():
     dt = time.perf_counter() - t0
     if sync_free and _rast.check_overflow():
         raise SystemExit("capacity overflow during the timed region: rerun with --exact-count")
+    if args.trace_steps > 0 and rank == 0 and not distributed:
+        fence()
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.trace_steps + 1)]
+        host = [time.perf_counter()]
+        evs[0].record()
+        for i in range(args.trace_steps):
+            step()
+            evs[i + 1].record()
+            host.append(time.perf_counter())
+        torch.cuda.synchronize()
+        log("per-step device ms behind a fence:", [round(evs[i].elapsed_time(evs[i + 1]), 3) for i in range(args.trace_steps)])
+        log("per-step host enqueue ms:", [round(1e3 * (host[i + 1] - host[i]), 3) for i in range(args.trace_steps)])
     _rast.set_sync_free(False)               # the per-stage profile below uses the exact path
     log(f"timed region: {dt / args.steps * 1e3:.3f} ms/step" + (" (capacity mode, no per-forward host sync)" if sync_free else ""))
     if distributed:

@@ -60,16 +60,17 @@ __device__ __forceinline__ float reduce_sep(float h, float hx, float hxx, float 
 
 enum {
     M_FMA, M_PKFMA, M_EXP, M_RCP, M_DPP_SHR, M_DPP_QUAD, M_DPP_MOV, M_SWAP32, M_SWAP16, M_CMP_CND, M_CNDMASK, M_READLANE,
-    M_SWZ_ADD, M_BPERM_ADD, M_SWZ_ONLY, M_CND_SALU, M_CND_VCC1, M_CMPX, M_WRITELANE, M_DPP_BANK, M_MOV, M_CND_E64_INV, M_CND_VCC_MIX, M_SEQ_R2, M_SEQ_SEP, M_COUNT
+    M_SWZ_ADD, M_BPERM_ADD, M_SWZ_ONLY, M_CND_SALU, M_CND_VCC1, M_CMPX, M_WRITELANE, M_DPP_BANK, M_MOV, M_CND_E64_INV, M_CND_VCC_MIX, M_FMA_LO32, M_FMA_ROW0, M_SEQ_R2, M_SEQ_SEP, M_COUNT
 };
 static const char* names[M_COUNT] = {
     "v_fma_f32", "v_pk_fma_f32", "v_exp_f32", "v_rcp_f32", "v_add_f32_dpp row_shr:1", "v_add_f32_dpp quad_perm",
     "v_mov_b32_dpp row_shr:1", "v_permlane32_swap", "v_permlane16_swap", "v_cmp+v_cndmask (pair)",
     "v_cndmask (SGPR mask)", "v_readlane+v_add (pair)", "ds_swizzle+v_add (pair)", "ds_bpermute+v_add (pair)",
     "ds_swizzle chain (LDS pipe)", "v_cndmask, mask rewritten by SALU", "v_cndmask x8 after ONE v_cmp", "v_cmpx + 7 plain under EXEC",
-    "v_writelane (SGPR lane sel)", "v_add_f32_dpp row_ror:8 bank_mask", "v_mov_b32", "v_cndmask_e64 x8, SGPR mask invariant", "v_cndmask_e32 vcc + v_fma alternating (pair)", "seq: reduce10 round 2", "seq: reduce x/y-separable"};
+    "v_writelane (SGPR lane sel)", "v_add_f32_dpp row_ror:8 bank_mask", "v_mov_b32", "v_cndmask_e64 x8, SGPR mask invariant", "v_cndmask_e32 vcc + v_fma alternating (pair)",
+    "v_fma_f32, EXEC = lanes 0..31 only", "v_fma_f32, EXEC = lanes 0..15 only", "seq: reduce10 round 2", "seq: reduce x/y-separable"};
 // wave-instructions of the row's kind per loop trip per wave (what the ns figure is divided by)
-static const double per_trip[M_COUNT] = {8, 8, 8, 8, 8, 8, 8, 8, 8, 16, 8, 16, 16, 16, 8, 8, 9, 8, 8, 8, 8, 8, 16, 1, 1};
+static const double per_trip[M_COUNT] = {8, 8, 8, 8, 8, 8, 8, 8, 8, 16, 8, 16, 16, 16, 8, 8, 9, 8, 8, 8, 8, 8, 16, 8, 8, 1, 1};
 
 template <int MODE>
 __global__ void __launch_bounds__(256) k(float* out, int iters, float seed, unsigned long long mask) {
@@ -180,6 +181,15 @@ __global__ void __launch_bounds__(256) k(float* out, int iters, float seed, unsi
             asm volatile("s_mov_b64 vcc, %0" :: "s"(mask) : "vcc");
             R8(F)
 #undef F
+        } else if (MODE == M_FMA_LO32 || MODE == M_FMA_ROW0) {
+            // does the SIMD skip the passes of a wave64 instruction whose lanes are all switched off?  (one asm block: the
+            // compiler never sees the narrowed EXEC)
+            const unsigned long long em = MODE == M_FMA_LO32 ? 0xFFFFFFFFull : 0xFFFFull;
+            asm volatile("s_mov_b64 exec, %8\n\t"
+                         "v_fma_f32 %0, %0, %9, %10\n\tv_fma_f32 %1, %1, %9, %10\n\tv_fma_f32 %2, %2, %9, %10\n\tv_fma_f32 %3, %3, %9, %10\n\t"
+                         "v_fma_f32 %4, %4, %9, %10\n\tv_fma_f32 %5, %5, %9, %10\n\tv_fma_f32 %6, %6, %9, %10\n\tv_fma_f32 %7, %7, %9, %10\n\t"
+                         "s_mov_b64 exec, -1"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "s"(em), "v"(c), "v"(d));
         } else if (MODE == M_SEQ_R2) {
             const float m = reduce10_r2(a0, a1, a2, a3, a4, a5, a6, a7, a0 + c, a1 + c, lane);
             a0 += m; a1 -= m; a2 += d; a3 += d; a4 += d; a5 += d; a6 += d; a7 += d;     // 8 plain ops of "other work"

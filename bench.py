@@ -317,7 +317,39 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    log(f"scene ready: P={args.gaussians} {W}x{H}; warmup {args.warmup}")
+    def live_ceilings():
+        """The two ceilings the roofline record quotes, measured live in this run: the plain-FMA issue rate (8 waves per SIMD, every
+        CU busy: mgs_debug_valu_ceiling) and a 512 MiB device-to-device copy (read + write counted).  Measured
+        BEFORE the warm-up and timed steps, on every rank: about 25 ms of device work, after which the device runs at its
+        operating clocks -- a 20-step timed region that starts from an idle device reads ~5 % low otherwise
+        (profiles/r04_bench_20steps_trace.log)."""
+        from monogs_amd import _lib as _L
+        lib = _L.load()
+        buf = torch.empty(2048 * 256, device=dev)
+        it_fma = 20000
+        for _ in range(2):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            _L.check(lib.mgs_debug_valu_ceiling(buf.data_ptr(), it_fma, torch.cuda.current_stream().cuda_stream), "valu_ceiling")
+            e1.record()
+            torch.cuda.synchronize()
+        fma = 8.0 * it_fma * 2048 * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        src = torch.empty(512 << 20, dtype=torch.uint8, device=dev)
+        dst = torch.empty_like(src)
+        dst.copy_(src)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            dst.copy_(src)
+        e1.record()
+        torch.cuda.synchronize()
+        copy = 10 * 2 * src.numel() / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del src, dst, buf
+        torch.cuda.empty_cache()
+        return fma, copy
+
+    state["ceilings"] = live_ceilings()
+    log(f"scene ready: P={args.gaussians} {W}x{H}; live ceilings: FMA {state['ceilings'][0]:.0f} G wave-inst/s, copy {state['ceilings'][1]:.0f} GB/s; warmup {args.warmup}")
     step()                                   # first step always exact: it records the capacity hint
     sync_free = not args.exact_count
     _rast.set_sync_free(sync_free)           # steady state: device-side instance count, no host sync per forward
@@ -425,21 +457,10 @@ def main():
             traffic = tj.get("blend_backward_bytes_per_launch")
         # ---- VALU view of the dominant kernel.  The data sheet's FP32 vector rate is one wave64 v_fma_f32 per 2 cycles per
         # SIMD (MI355X_MICROARCH.md: "v_fma_f32 (wave64): 2 cyc"; 157.3 TFLOP/s / 128 flop): 1024 x 2.4e9 / 2 = 1228.8 G
-        # wave-inst/s.  What the chip sustains on plain FMAs under this load is measured LIVE below (it does not hold 2.4 GHz).
+        # wave-inst/s.  What the chip sustains on plain FMAs under this load is measured LIVE at the start of the run (it does not hold 2.4 GHz).
         # Neither is the bound that binds: the kernel's instructions are not all plain -- the issue model prices the static mix
         # of its hot loop (profiles/isa_mix.json) with the measured per-class issue times (profiles/valu_costs.json).
-        from monogs_amd import _lib as _L
-        lib = _L.load()
-        buf = torch.empty(2048 * 256, device=dev)
-        it_fma = 20000
-        for _ in range(2):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            _L.check(lib.mgs_debug_valu_ceiling(buf.data_ptr(), it_fma, torch.cuda.current_stream().cuda_stream), "valu_ceiling")
-            e1.record()
-            torch.cuda.synchronize()
-        fma_ginst = 8.0 * it_fma * 2048 * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
-        del buf
+        fma_ginst, copy_gbs = state["ceilings"]
         surv = max(1, walk["survivors"])
         t_bwd = stages["blend_bwd_ms"] * 1e-3
         ns_meas = t_bwd * 1e9 * 1024 / surv                 # SIMD-time per survivor: the launch's survivors spread over 1024 SIMDs
@@ -470,18 +491,6 @@ def main():
                          "frac_of_spec_valu_peak": round(insts / t_bwd / 1e9 / 1228.8, 4),
                          "frac_of_measured_fma_rate": round(insts / t_bwd / 1e9 / fma_ginst, 4),
                          "pmc_source": "profiles/pmc_valu.json (rocprofv3 --pmc, stamped with the kernel-source hash)"})
-        # measured device-copy ceiling from the same run: 512 MiB device-to-device copy, read + write counted
-        src = torch.empty(512 << 20, dtype=torch.uint8, device=dev)
-        dst = torch.empty_like(src)
-        dst.copy_(src)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(10):
-            dst.copy_(src)
-        e1.record()
-        torch.cuda.synchronize()
-        copy_gbs = 10 * 2 * src.numel() / (e0.elapsed_time(e1) * 1e-3) / 1e9
-        del src, dst
         # all stages: SURVEY.md 8d per-stage algorithmic bytes (one ideal sort pass each for the two sorts)
         b_all = (44 * P + 8 * P + 52 * Pv) + 8 * P + (16 * Pv + 12 * R) + 24 * R + (8 * R + 8 * ((W + 15) // 16) * ((H + 15) // 16)) \
             + b_fwd + b_bwd + (44 * P + 40 * Pv + 68 * Pv + 24)
@@ -588,6 +597,8 @@ def main():
                                    f"(SURVEY.md 8d), one keyframe per GPU",
                        "gaussians": args.gaussians, "width": W, "height": H,
                        "instance_count": "device-side (capacity mode, overflow checked)" if sync_free else "host read-back per forward",
+                       "before_the_warmup": "the two live ceilings of the roofline record (plain-FMA issue rate, 512 MiB device copy: ~25 ms of "
+                                            "device work) are measured before the W warm-up steps, not after the timed region",
                        "parallelism": f"keyframe-per-gpu x{world}" + (f" + RCCL all-reduce of 12 floats/Gaussian in {bucket.last_collectives} collective(s)" if bucket is not None else "")
                        + (" [REHEARSAL: ranks share a device, collectives over gloo]" if rehearsal else "")},
             "stages_ms": stages,

@@ -320,9 +320,7 @@ def main():
     def live_ceilings():
         """The two ceilings the roofline record quotes, measured live in this run: the plain-FMA issue rate (8 waves per SIMD, every
         CU busy: mgs_debug_valu_ceiling) and a 512 MiB device-to-device copy (read + write counted).  Measured
-        BEFORE the warm-up and timed steps, on every rank: about 25 ms of device work, after which the device runs at its
-        operating clocks -- a 20-step timed region that starts from an idle device reads ~5 % low otherwise
-        (profiles/r04_bench_20steps_trace.log)."""
+        after the timed region (rank 0 only)."""
         from monogs_amd import _lib as _L
         lib = _L.load()
         buf = torch.empty(2048 * 256, device=dev)
@@ -348,8 +346,7 @@ def main():
         torch.cuda.empty_cache()
         return fma, copy
 
-    state["ceilings"] = live_ceilings()
-    log(f"scene ready: P={args.gaussians} {W}x{H}; live ceilings: FMA {state['ceilings'][0]:.0f} G wave-inst/s, copy {state['ceilings'][1]:.0f} GB/s; warmup {args.warmup}")
+    log(f"scene ready: P={args.gaussians} {W}x{H}; warmup {args.warmup}")
     step()                                   # first step always exact: it records the capacity hint
     sync_free = not args.exact_count
     _rast.set_sync_free(sync_free)           # steady state: device-side instance count, no host sync per forward
@@ -357,11 +354,25 @@ def main():
         step()
     fence()
     log("warmup done; timing", args.steps, "steps")
+    # (short runs: an event per step, so that the line's reader can see how far from the steady state the run was -- the two
+    #  blend kernels take ~15 steps from process start to reach their speed, whatever ran on the device before:
+    #  profiles/r04_warmup_probe.txt)
+    trace = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)] if (args.steps <= 64 and rank == 0) else None
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    if trace:
+        trace[0].record()
+    for i in range(args.steps):
         step()
+        if trace:
+            trace[i + 1].record()            # (short runs only: an event record per step, ~1 us of stream time)
+            state.setdefault("reserved", []).append(torch.cuda.memory_reserved())
+    t_host = time.perf_counter() - t0        # (diagnostic: when the host had queued the last step)
     fence()
     dt = time.perf_counter() - t0
+    if trace:
+        log("timed region, device ms per step:", [round(trace[i].elapsed_time(trace[i + 1]), 3) for i in range(args.steps)])
+        log("timed region, GiB reserved by the caching allocator after each step:", [round(v / 2**30, 2) for v in state.get("reserved", [])])
+    log(f"timed region: host had queued the {args.steps} steps after {t_host * 1e3:.2f} ms, the device was done after {dt * 1e3:.2f} ms")
     if sync_free and _rast.check_overflow():
         raise SystemExit("capacity overflow during the timed region: rerun with --exact-count")
     if args.trace_steps > 0 and rank == 0 and not distributed:
@@ -457,10 +468,10 @@ def main():
             traffic = tj.get("blend_backward_bytes_per_launch")
         # ---- VALU view of the dominant kernel.  The data sheet's FP32 vector rate is one wave64 v_fma_f32 per 2 cycles per
         # SIMD (MI355X_MICROARCH.md: "v_fma_f32 (wave64): 2 cyc"; 157.3 TFLOP/s / 128 flop): 1024 x 2.4e9 / 2 = 1228.8 G
-        # wave-inst/s.  What the chip sustains on plain FMAs under this load is measured LIVE at the start of the run (it does not hold 2.4 GHz).
+        # wave-inst/s.  What the chip sustains on plain FMAs under this load is measured LIVE below (it does not hold 2.4 GHz).
         # Neither is the bound that binds: the kernel's instructions are not all plain -- the issue model prices the static mix
         # of its hot loop (profiles/isa_mix.json) with the measured per-class issue times (profiles/valu_costs.json).
-        fma_ginst, copy_gbs = state["ceilings"]
+        fma_ginst, copy_gbs = live_ceilings()
         surv = max(1, walk["survivors"])
         t_bwd = stages["blend_bwd_ms"] * 1e-3
         ns_meas = t_bwd * 1e9 * 1024 / surv                 # SIMD-time per survivor: the launch's survivors spread over 1024 SIMDs
@@ -597,8 +608,6 @@ def main():
                                    f"(SURVEY.md 8d), one keyframe per GPU",
                        "gaussians": args.gaussians, "width": W, "height": H,
                        "instance_count": "device-side (capacity mode, overflow checked)" if sync_free else "host read-back per forward",
-                       "before_the_warmup": "the two live ceilings of the roofline record (plain-FMA issue rate, 512 MiB device copy: ~25 ms of "
-                                            "device work) are measured before the W warm-up steps, not after the timed region",
                        "parallelism": f"keyframe-per-gpu x{world}" + (f" + RCCL all-reduce of 12 floats/Gaussian in {bucket.last_collectives} collective(s)" if bucket is not None else "")
                        + (" [REHEARSAL: ranks share a device, collectives over gloo]" if rehearsal else "")},
             "stages_ms": stages,

@@ -37,7 +37,7 @@ GeometryState GeometryState::carve(void* base, int P) {
     g.clamped = (uint8_t*)take(p, (size_t)P * 4);
     g.rect = (uint2*)take(p, (size_t)P * sizeof(uint2));
     g.rect_sorted = (uint2*)take(p, (size_t)P * sizeof(uint2));
-    g.scan_status = (uint64_t*)take(p, SCAN_SMALL_MAX_BLOCKS * sizeof(uint64_t));
+    g.scan_status = (uint64_t*)take(p, (SCAN_SMALL_MAX_BLOCKS + 1) * sizeof(uint64_t));
     g.tile_hist = (uint32_t*)take(p, 4 * 256 * sizeof(uint32_t));
     g.sort_temp_bytes = radix_depth_temp_bytes((uint64_t)P);
     g.sort_temp = take(p, g.sort_temp_bytes);           // 256-aligned, directly behind tile_hist
@@ -187,7 +187,7 @@ int mgs_forward_preprocess(const mgs_camera* cam, int32_t P, const float* means3
     const bool exclusive = (cam->flags & MGS_FLAG_EXCLUSIVE_DEVICE) != 0;
     if (int rc = launch_depth_sort(g, P, depth_sort_payload(P, cam->image_width, cam->image_height), s, exclusive)) return rc;
     tm.mark();
-    if (int rc = launch_scan(g, P, s)) return rc;
+    if (int rc = launch_scan(g, P, s, exclusive)) return rc;
     tm.mark();
     if (num_rendered) {
         uint32_t total = 0, sort_errors[RADIX_ERROR_WORDS] = {0, 0, 0, 0};
@@ -364,6 +364,8 @@ int mgs_debug_valu_ceiling(float* out, int32_t iters, void* stream) {
 
 int mgs_debug_set_radix_spin_limit(uint32_t limit) { return set_radix_spin_limit(limit); }
 
+static int g_opt_debug_sort_exclusive = 0;   // mgs_debug_set_option("debug_sort_exclusive", 1): mgs_debug_sort_pairs sorts as under
+                                             // MGS_FLAG_EXCLUSIVE_DEVICE (block ids as tile ids)
 size_t mgs_debug_sort_temp_bytes(uint64_t n, int32_t bits) { return radix_temp_bytes(n, bits); }
 int mgs_debug_sort_pairs(uint32_t* keys, uint32_t* vals, uint32_t* keys_alt, uint32_t* vals_alt, uint64_t n, int32_t bits,
                          void* temp, void* stream) {
@@ -373,7 +375,9 @@ int mgs_debug_sort_pairs(uint32_t* keys, uint32_t* vals, uint32_t* keys_alt, uin
     }
     if (n == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
-    if (int rc = radix_sort_pairs(keys, vals, keys_alt, vals_alt, n, bits, temp, s)) return rc;
+    if (int rc = radix_sort_pairs(keys, vals, keys_alt, vals_alt, n, bits, temp, s, nullptr, false, nullptr, nullptr, nullptr, false,
+                                  g_opt_debug_sort_exclusive != 0))
+        return rc;
     if (radix_result_in_b(bits)) {
         MGS_HIP(hipMemcpyAsync(keys, keys_alt, n * 4, hipMemcpyDeviceToDevice, s));
         MGS_HIP(hipMemcpyAsync(vals, vals_alt, n * 4, hipMemcpyDeviceToDevice, s));
@@ -388,6 +392,7 @@ int mgs_debug_sort_pairs(uint32_t* keys, uint32_t* vals, uint32_t* keys_alt, uin
 int mgs_debug_set_option(const char* name, int64_t value) {
     if (name && !strcmp(name, "radix_scanned")) { g_opt_radix_scanned = (int)value; return 0; }
     if (name && !strcmp(name, "radix_ballot_rank")) { g_opt_radix_ballot_rank = (int)value; return 0; }
+    if (name && !strcmp(name, "debug_sort_exclusive")) { g_opt_debug_sort_exclusive = (int)value; return 0; }
     if (name && !strcmp(name, "dup_slot_major")) { g_opt_dup_slot_major = (int)value; return 0; }
     if (name && !strcmp(name, "blend_bwd_transposed")) { g_opt_blend_bwd_transposed = (int)value; return 0; }
     if (name && !strcmp(name, "scan_small")) { g_opt_scan_small = (int)value; return 0; }

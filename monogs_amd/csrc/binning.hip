@@ -105,25 +105,33 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_blocks_kernel(uint32_t* blo
 
 // ONE launch for P <= SCAN_SMALL_MAX_BLOCKS * SCAN_ITEMS (every SLAM-sized map): each workgroup publishes its total as a
 // self-describing 8-byte word {1 << 63 | total} (one relaxed agent-scope store, polled with relaxed agent-scope loads:
-// the radix sort's protocol), lane j of its first wave waits for workgroup j < blockIdx.x, the wave adds them up.  All
-// <= 64 workgroups are co-resident (one per CU), so nobody waits for a workgroup that has not started; the spin is
-// bounded anyway and raises the depth sort's error word (the consumers of the scan are the consumers of that sort).
-// out[] then holds GLOBAL inclusive sums; the grand total still goes to block_sums[nblocks].
+// the radix sort's protocol), lane j of its first wave waits for block j < its own, the wave adds them up.  Which block
+// of the input a workgroup takes is decided by an atomic ticket (status[SCAN_SMALL_MAX_BLOCKS], zeroed with the status
+// words), as in the radix sort: a workgroup then only ever waits for workgroups that have already started, whatever
+// else shares the device.  Under MGS_FLAG_EXCLUSIVE_DEVICE the <= 64 workgroups are co-resident (one per CU) and the
+// block id serves.  The spin is bounded anyway and raises the depth sort's error word (the consumers of the scan are
+// the consumers of that sort).  out[] then holds GLOBAL inclusive sums; the grand total goes to block_sums[nblocks].
 constexpr uint32_t SCAN_SPIN_LIMIT = 1u << 22;
 __global__ void __launch_bounds__(SCAN_THREADS) scan_small_kernel(const uint2* __restrict__ rects, uint32_t* out,
                                                                   uint32_t* block_sums, uint64_t* status, int n, int nb,
-                                                                  uint32_t* err) {
+                                                                  uint32_t* err, int ticketed) {
     __shared__ uint32_t smem[8];
-    __shared__ uint32_t s_prefix;
+    __shared__ uint32_t s_prefix, s_bid;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int cbase = blockIdx.x * SCAN_ITEMS + wv * (SCAN_PER_THREAD * WAVE);
+    int bid = (int)blockIdx.x;
+    if (ticketed) {
+        if (threadIdx.x == 0) s_bid = atomicAdd((uint32_t*)(status + SCAN_SMALL_MAX_BLOCKS), 1u);
+        __syncthreads();
+        bid = (int)s_bid;
+    }
+    const int cbase = bid * SCAN_ITEMS + wv * (SCAN_PER_THREAD * WAVE);
     uint32_t incl[SCAN_PER_THREAD];
     const uint32_t total = scan_block_rows(rects, n, cbase, lane, wv, incl, smem);
     if (threadIdx.x == 0)
-        __hip_atomic_store(status + blockIdx.x, (1ull << 63) | (uint64_t)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(status + bid, (1ull << 63) | (uint64_t)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (threadIdx.x < WAVE) {
         uint32_t before = 0;
-        if ((int)threadIdx.x < (int)blockIdx.x) {
+        if ((int)threadIdx.x < bid) {
             uint64_t w = 0;
             uint32_t spins = 0;
             while (true) {
@@ -144,7 +152,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_small_kernel(const uint2* _
         const int idx = cbase + i * WAVE + lane;
         if (idx < n) out[idx] = incl[i] + s_prefix;
     }
-    if (threadIdx.x == 0 && (int)blockIdx.x == nb - 1) block_sums[nb] = s_prefix + total;
+    if (threadIdx.x == 0 && bid == nb - 1) block_sums[nb] = s_prefix + total;
 }
 int g_opt_scan_small = -1;          // mgs_debug_set_option("scan_small", -1 | 0 | 1): 0 = always the two-launch scan
 bool scan_is_small(int P) { return g_opt_scan_small != 0 && scan_nblocks(P) <= SCAN_SMALL_MAX_BLOCKS; }
@@ -154,12 +162,13 @@ bool scan_is_small(int P) { return g_opt_scan_small != 0 && scan_nblocks(P) <= S
 
 // (Measured and rejected: a single-workgroup scan for small P -- 1024 threads x a serial run of dependent
 //  gathers each -- took ~300 us at P = 38 k against ~15 us for the three launches below: latency, not launches.)
-int launch_scan(const GeometryState& g, int P, hipStream_t s) {
+int launch_scan(const GeometryState& g, int P, hipStream_t s, bool exclusive) {
     if (P == 0) return 0;
     const int nb = scan_nblocks(P);
     if (scan_is_small(P)) {
         hipLaunchKernelGGL(scan_small_kernel, dim3(nb), dim3(SCAN_THREADS), 0, s, g.rect_sorted, g.point_offsets, g.scan_blocks,
-                           g.scan_status, P, nb, const_cast<uint32_t*>(radix_depth_error_flag(g.sort_temp, (uint64_t)P)));
+                           g.scan_status, P, nb, const_cast<uint32_t*>(radix_depth_error_flag(g.sort_temp, (uint64_t)P)),
+                           exclusive ? 0 : 1);
         MGS_HIP(hipGetLastError());
         return 0;
     }

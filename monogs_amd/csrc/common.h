@@ -134,7 +134,7 @@ struct GeometryState {
                               //     which the depth sort carries along as a payload, the second half its ping-pong partner
     uint2* rect_sorted;       // [P] the same in depth order: written by the last pass of the depth sort, so that the
                               //     scan and duplicate read it coalesced instead of gathering through perm[]
-    uint64_t* scan_status;    // [SCAN_SMALL_MAX_BLOCKS] block totals of the single-launch scan (zeroed by preprocess)
+    uint64_t* scan_status;    // [SCAN_SMALL_MAX_BLOCKS + 1] block totals of the single-launch scan + its ticket (zeroed by preprocess)
     uint32_t* tile_hist;      // [4][256] digit counts of the TILE sort's keys, counted by duplicate_kernel while it emits
                               //          them (zeroed by preprocess; lives here because the binning scratch only exists
                               //          once the instance count is known)
@@ -203,7 +203,7 @@ constexpr int TAU_SLOTS = 256;              // one 64-byte line each
 inline float* backward_grad_acc(void* scratch) { return (float*)align_up((size_t)scratch, 256); }
 inline float* backward_tau_part(void* scratch, int P) { return backward_grad_acc(scratch) + (size_t)P * GRAD_FLOATS; }
 inline float* backward_tau_out(void* scratch, int P) { return backward_tau_part(scratch, P) + (size_t)TAU_SLOTS * 16; }
-int launch_scan(const GeometryState& g, int P, hipStream_t s);
+int launch_scan(const GeometryState& g, int P, hipStream_t s, bool exclusive = false);
 // `r_cap`: capacity of the binning buffers; `count` (device): [0] live instance count min(R, r_cap), [1] overflow flag
 int launch_duplicate(const mgs_camera& cam, int P, const GeometryState& g, const BinningState& b, uint64_t r_cap,
                      int32_t* n_touched, const ImageState& img, uint64_t sort_n, int sort_bits, uint32_t* count,

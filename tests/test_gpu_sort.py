@@ -71,6 +71,23 @@ def test_atomic_ranking_equals_ballot_ranking(native_lib, n):
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
 
 
+@pytest.mark.parametrize("n", [1, 63, 1025, 150_001, 196_700, 500_003])
+@pytest.mark.parametrize("kind,bits", [("five", 16), ("depth", 32)])
+def test_block_ids_as_tile_ids_on_an_exclusive_device(native_lib, n, kind, bits):
+    """Tile ids come from an atomic ticket; under MGS_FLAG_EXCLUSIVE_DEVICE a one-sweep sort of at most 256 tiles takes block
+    ids instead (rs_run).  Same stable order, no error word raised (the entry point returns 2 if one is)."""
+    gen = torch.Generator().manual_seed(n * 17 + bits)
+    keys = _keys(kind, n, bits, gen).to(DEV)
+    k32 = keys.to(torch.int32) if bits < 32 else (keys - ((keys >> 31) << 32)).to(torch.int32)
+    native_lib.mgs_debug_set_option(b"debug_sort_exclusive", 1)
+    try:
+        got = _sort(native_lib, k32, bits)
+    finally:
+        native_lib.mgs_debug_set_option(b"debug_sort_exclusive", 0)
+    ref_k, ref_v = torch.sort(keys, stable=True)
+    assert torch.equal(got[0].long() & 0xFFFFFFFF, ref_k) and torch.equal(got[1].long(), ref_v)
+
+
 def test_both_offset_paths_agree_on_a_large_sort(native_lib):
     gen = torch.Generator().manual_seed(5)
     keys = _keys("depth", 2_000_000, 32, gen).to(DEV)

@@ -38,6 +38,12 @@ def parse():
                          "utilisation sampler; c4: 200 -- its steps are optimiser iterations, so a long run is a different "
                          "map at the end than at the start)")
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--settle-steps", type=int, default=60,
+                    help="c5: un-timed steps of the same workload run BEFORE the --warmup steps, so that a short run is timed "
+                         "with the chip in the power state a long one reaches by itself: the two VALU-bound blend kernels get "
+                         "~6 %% faster over the first ~40 ms of sustained load after process start (profiles/r04_warmup_probe.txt, "
+                         "profiles/r04_bench_settle.log).  0 = off.  Reported in the line as config.settle_steps; the timed "
+                         "region is still exactly --steps steps between two fences")
     ap.add_argument("--gaussians", type=int, default=2_000_000)
     ap.add_argument("--intrinsics", default="davis_1080p")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -350,13 +356,12 @@ def main():
     step()                                   # first step always exact: it records the capacity hint
     sync_free = not args.exact_count
     _rast.set_sync_free(sync_free)           # steady state: device-side instance count, no host sync per forward
-    for _ in range(max(0, args.warmup - 1)):
+    for _ in range(max(0, args.settle_steps) + max(0, args.warmup - 1)):
         step()
     fence()
-    log("warmup done; timing", args.steps, "steps")
+    log(f"warmup done ({args.settle_steps} settle + {args.warmup} warm-up steps); timing", args.steps, "steps")
     # (short runs: an event per step, so that the line's reader can see how far from the steady state the run was -- the two
-    #  blend kernels take ~15 steps from process start to reach their speed, whatever ran on the device before:
-    #  profiles/r04_warmup_probe.txt)
+    #  blend kernels take ~40 steps of sustained load from process start to reach their speed, see --settle-steps)
     trace = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)] if (args.steps <= 64 and rank == 0) else None
     t0 = time.perf_counter()
     if trace:
@@ -606,7 +611,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{'C5' if is_c5 else 'custom'}: {args.gaussians} Gaussians, {W}x{H}, fwd+bwd, seeded synthetic map "
                                    f"(SURVEY.md 8d), one keyframe per GPU",
-                       "gaussians": args.gaussians, "width": W, "height": H,
+                       "gaussians": args.gaussians, "width": W, "height": H, "settle_steps": args.settle_steps,
                        "instance_count": "device-side (capacity mode, overflow checked)" if sync_free else "host read-back per forward",
                        "parallelism": f"keyframe-per-gpu x{world}" + (f" + RCCL all-reduce of 12 floats/Gaussian in {bucket.last_collectives} collective(s)" if bucket is not None else "")
                        + (" [REHEARSAL: ranks share a device, collectives over gloo]" if rehearsal else "")},

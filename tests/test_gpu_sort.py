@@ -88,6 +88,24 @@ def test_block_ids_as_tile_ids_on_an_exclusive_device(native_lib, n, kind, bits)
     assert torch.equal(got[0].long() & 0xFFFFFFFF, ref_k) and torch.equal(got[1].long(), ref_v)
 
 
+@pytest.mark.parametrize("n", [600_011, 1_200_007, 4_300_001])
+def test_xcd_band_tile_order_changes_nothing(native_lib, n):
+    """The counted-tiles passes take one contiguous band of tiles per XCD (workgroup b -> tile (b mod 8) bands + b / 8) instead
+    of tile = block id: only who writes which part of the output changes, not one word of it."""
+    gen = torch.Generator().manual_seed(n + 3)
+    keys = _keys("depth", n, 32, gen).to(DEV)
+    k32 = (keys - ((keys >> 31) << 32)).to(torch.int32)
+    a = _sort(native_lib, k32, 32)
+    native_lib.mgs_debug_set_option(b"radix_xcd_band", 0)
+    try:
+        b = _sort(native_lib, k32, 32)
+    finally:
+        native_lib.mgs_debug_set_option(b"radix_xcd_band", 1)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    ref_k, ref_v = torch.sort(keys, stable=True)
+    assert torch.equal(a[0].long() & 0xFFFFFFFF, ref_k) and torch.equal(a[1].long(), ref_v)
+
+
 def test_both_offset_paths_agree_on_a_large_sort(native_lib):
     gen = torch.Generator().manual_seed(5)
     keys = _keys("depth", 2_000_000, 32, gen).to(DEV)

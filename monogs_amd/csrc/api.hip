@@ -392,6 +392,7 @@ int mgs_debug_sort_pairs(uint32_t* keys, uint32_t* vals, uint32_t* keys_alt, uin
 int mgs_debug_set_option(const char* name, int64_t value) {
     if (name && !strcmp(name, "radix_scanned")) { g_opt_radix_scanned = (int)value; return 0; }
     if (name && !strcmp(name, "radix_ballot_rank")) { g_opt_radix_ballot_rank = (int)value; return 0; }
+    if (name && !strcmp(name, "radix_tile_items")) { g_opt_radix_tile_items = (int)value; return 0; }
     if (name && !strcmp(name, "radix_xcd_band")) { g_opt_radix_xcd_band = (int)value; return 0; }
     if (name && !strcmp(name, "debug_sort_exclusive")) { g_opt_debug_sort_exclusive = (int)value; return 0; }
     if (name && !strcmp(name, "dup_slot_major")) { g_opt_dup_slot_major = (int)value; return 0; }

@@ -122,8 +122,11 @@ static inline bool rs_scanned(uint64_t n) {
 // lives (tile sort at C5, 5.27 M pairs = 1287 tiles of 4096 against 1024 resident: tile starts at 0 and at 14 us).  4096-pair
 // tiles: 84-92 VGPRs + 24 KB of LDS = 4-5 workgroups per CU; 3072-pair tiles: 72 VGPRs + 20 KB = 7 per CU (1792), and 1716
 // tiles at C5 (82.7 us against 85.9; 2048-pair tiles lose it again to the doubled count tables, 104.6 us).
+int g_opt_radix_tile_items = 0;     // mgs_debug_set_option("radix_tile_items", 8 | 12 | 16): pairs per thread on the counted-tiles path (0: by size)
 static inline int rs_tile_items(uint64_t n, bool scanned) {
     if (!scanned) return rs_items(n);
+    if (g_opt_radix_tile_items == RS_ITEMS_MID || g_opt_radix_tile_items == RS_ITEMS_WIDE || g_opt_radix_tile_items == RS_ITEMS)
+        return g_opt_radix_tile_items;
     return n > 1024ull * RS_THREADS * RS_ITEMS ? RS_ITEMS_WIDE : RS_ITEMS;
 }
 static inline uint32_t rs_tiles(uint64_t n, bool scanned) {
@@ -520,16 +523,19 @@ __global__ void __launch_bounds__(RS_THREADS, (SCANNED && ITEMS == RS_ITEMS_WIDE
         for (int q = 0; q < a.pass; ++q) failed |= a.error[q];
         if (failed) return;
     }
+    const uint32_t n_live = a.n_dev ? min(a.n, a.n_dev[0]) : a.n;
     if (t == 0) {
         uint32_t id = blockIdx.x;
-        if (SCANNED && a.xcd_band) {
+        if (a.xcd_band) {
             // Workgroups are dealt round-robin to the 8 XCDs, each with an L2 of its own.  The runs that neighbouring tiles
             // write for one digit are adjacent in memory and short (tile sort at C5: 3072 pairs / 256 digits = 48 bytes of
             // keys per run, 32 bytes in a 512-digit depth pass), so with tile = block id every 128-byte line of the output
-            // is written in pieces by several L2s.  One contiguous band of tiles per XCD lets the pieces meet in ONE L2
-            // before the line leaves it: tile sort 83 -> 58 us, depth sort 102 -> 94 us at C5 (round 4).
-            const uint32_t q = a.tiles >> 3, r = a.tiles & 7u, x = id & 7u, j = id >> 3;
-            id = x * q + min(x, r) + j;
+            // is written in pieces by several L2s.  One contiguous band of the LIVE tiles per XCD lets the pieces meet in
+            // ONE L2 before the line leaves it: tile sort 83 -> 58 us, depth sort 102 -> 94 us at C5 (round 4).  (Capacity
+            // mode launches tiles for the capacity: banding those would leave the XCDs of the last bands without work.)
+            const uint32_t live = (n_live + (uint32_t)TILE_PAIRS - 1) / (uint32_t)TILE_PAIRS;
+            const uint32_t q = live >> 3, r = live & 7u, x = id & 7u, j = id >> 3;
+            id = j < q + (x < r ? 1u : 0u) ? x * q + min(x, r) + j : 0xFFFFFFFFu;      // (its XCD's band is handed out: nothing to do)
         }
         s_tile = (!SCANNED && a.ticket) ? atomicAdd(a.ticket, 1u) : id;   // a returning atomic is a ~2 us round trip
     }
@@ -539,8 +545,8 @@ __global__ void __launch_bounds__(RS_THREADS, (SCANNED && ITEMS == RS_ITEMS_WIDE
         for (int j = 0; j < DPT; ++j) wave_hist[w][t * DPT + j] = 0;
     __syncthreads();
     const uint32_t tile = s_tile;
+    if (tile == 0xFFFFFFFFu) return;
     const uint32_t tile_start = tile * (uint32_t)TILE_PAIRS;
-    const uint32_t n_live = a.n_dev ? min(a.n, a.n_dev[0]) : a.n;
     if (tile_start >= n_live) return;        // capacity mode: tiles past the live count have nothing to do
                                              // (tickets are dense, so no live tile ever looks back at them)
     const uint32_t tile_n = min((uint32_t)TILE_PAIRS, n_live - tile_start);
@@ -886,6 +892,7 @@ template <int DB, bool PAYLOAD>
 static void rs_launch_pass_items(const RsPassArgs& a, int items, bool scanned, uint32_t tiles, bool ballot, hipStream_t s) {
     if (scanned) {
         if (items == RS_ITEMS_WIDE) rs_launch_pass<RS_ITEMS_WIDE, DB, true, PAYLOAD>(a, tiles, ballot, s);
+        else if (items == RS_ITEMS_MID) rs_launch_pass<RS_ITEMS_MID, DB, true, PAYLOAD>(a, tiles, ballot, s);
         else rs_launch_pass<RS_ITEMS, DB, true, PAYLOAD>(a, tiles, ballot, s);
     } else if constexpr (!PAYLOAD && DB == 8) {        // (payloads and 9-bit digits only exist on the counted-tiles path)
         if (items == RS_ITEMS_SMALL) rs_launch_pass<RS_ITEMS_SMALL, 8, false, false>(a, tiles, ballot, s);
@@ -947,6 +954,9 @@ static int rs_run(const RsPlan& pl, const RsBuffers& b, uint64_t n, void* temp, 
         a.ticket = (exclusive && tiles <= 256u) ? nullptr : t.tickets + p;
         a.error = t.error;
         a.pass = p;
+        // (counted tiles only: no tile waits for another there.  One sweep with block ids as tile ids -- an exclusive device,
+        //  every tile resident -- could take it too and was measured: a replayed tracking iteration 215.5 against 217.7 us,
+        //  inside the noise: those passes are bound by their round trips, not by the memory side)
         a.xcd_band = (scanned && g_opt_radix_xcd_band != 0) ? 1 : 0;
         a.counts = t.counts; a.sums = t.sums + (size_t)p * tree.sum_rows * pl.radix;
         a.tree = ta;
@@ -966,6 +976,8 @@ static int rs_run(const RsPlan& pl, const RsBuffers& b, uint64_t n, void* temp, 
             h.wide = t.wide; h.detect = (pl.depth && p == 0) ? 1 : 0; h.only_if_wide = a.cond == 2 ? 1 : 0;
             if (items == RS_ITEMS_WIDE) {
                 if (pl.db[p] == 9) rs_launch_tile_hist<RS_ITEMS_WIDE, 9>(h, s); else rs_launch_tile_hist<RS_ITEMS_WIDE, 8>(h, s);
+            } else if (items == RS_ITEMS_MID) {
+                if (pl.db[p] == 9) rs_launch_tile_hist<RS_ITEMS_MID, 9>(h, s); else rs_launch_tile_hist<RS_ITEMS_MID, 8>(h, s);
             } else {
                 if (pl.db[p] == 9) rs_launch_tile_hist<RS_ITEMS, 9>(h, s); else rs_launch_tile_hist<RS_ITEMS, 8>(h, s);
             }

@@ -162,7 +162,11 @@ int mgs_debug_set_radix_spin_limit(uint32_t limit);
  * pass, no waiting between workgroups -- honoured from 64 k pairs), "radix_ballot_rank" (1 = rank with wave ballots instead of
  * returning LDS atomics: the reference the sort tests compare with), "scan_small" (0 = the two-launch scan at every size),
  * "dup_slot_major" (0 / 1 = the duplicate kernel's emission balanced by Gaussians / by output slots at every size),
- * "knn_grid_min" (Morton-box kNN from this many points).  Nothing on the launch path consults the environment. */
+ * "knn_grid_min" (Morton-box kNN from this many points), "blend_bwd_transposed" (0 = the per-survivor blend backward),
+ * "radix_xcd_band" (0 = counted tiles in block-id order instead of one contiguous band of tiles per XCD), "radix_tile_items"
+ * (8 | 12 | 16 pairs per thread on the counted-tiles path, 0 = by size; set it before any scratch is sized),
+ * "debug_sort_exclusive" (1 = mgs_debug_sort_pairs sorts as under MGS_FLAG_EXCLUSIVE_DEVICE).  Nothing on the launch path
+ * consults the environment. */
 int mgs_debug_set_option(const char* name, int64_t value);
 
 /* Test entry: the library's stable radix sort of n (key, value) pairs on key bits [0, bits) -- what the forward runs on

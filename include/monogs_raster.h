@@ -65,11 +65,11 @@ typedef struct mgs_camera {
 
 /* mgs_camera.flags.
  * MGS_FLAG_EXCLUSIVE_DEVICE: the caller guarantees that NO other grid runs beside this call's kernels -- one process on the
- * device, one stream (a pose-tracking loop, a captured single-stream iteration).  The small radix sorts (<= 256 tiles) then
- * take their tile ids from the block index, which saves a returning atomic (~2 us) per pass.  Without the flag -- the
- * default, and what MonoGS's topology needs: tracker, mapper and viewer processes share one GPU
- * (/root/reference/slam.py:102-179), and a mapping window renders its keyframes on a stream each -- every sort hands out
- * tile ids by an atomic ticket, so a tile only ever waits for tiles that have already started: forward progress does not
+ * device, one stream (a pose-tracking loop, a captured single-stream iteration).  The small radix sorts (<= 256 tiles) and
+ * the single-launch scan then take their tile / block ids from the block index, which saves a returning atomic (~2 us) per
+ * launch.  Without the flag -- the default, and what MonoGS's topology needs: tracker, mapper and viewer processes share one GPU
+ * (/root/reference/slam.py:102-179), and a mapping window renders its keyframes on a stream each -- every such launch hands out
+ * its ids by an atomic ticket, so a workgroup only ever waits for workgroups that have already started: forward progress does not
  * depend on where, or in which order, the hardware places workgroups of competing grids. */
 #define MGS_FLAG_EXCLUSIVE_DEVICE 1
 

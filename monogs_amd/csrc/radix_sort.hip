@@ -518,7 +518,7 @@ __global__ void __launch_bounds__(RS_THREADS, (SCANNED && ITEMS == RS_ITEMS_WIDE
         // A timed-out look-back in an EARLIER pass left part of this pass's input unwritten: ranking it against the
         // histogram of the original keys could place pairs past the end of the buffers.  Such a pass does nothing (the
         // words of earlier passes cannot change while this one runs, so every tile takes the same decision), and the
-        // consumers of the sort treat a raised flag as "no output" (duplicate_kernel, ranges_kernel).
+        // consumers of the sort treat a raised flag as "no output" (duplicate_kernel, blend_forward_kernel).
         uint32_t failed = 0;
         for (int q = 0; q < a.pass; ++q) failed |= a.error[q];
         if (failed) return;

@@ -226,6 +226,14 @@ int mgs_backward(const mgs_camera* cam, int32_t P, uint64_t num_rendered,
 #define MGS_VALU_CEILING_BLOCKS 2048
 int mgs_debug_valu_ceiling(float* out, int32_t iters, void* stream);
 
+/* Measurement hook: until switched off again, every forward records fwd_start right before and fwd_end right after its
+ * blend-forward launch, every mgs_backward bwd_start / bwd_end around its blend-backward launch, on the call's stream
+ * (hipEvent_t handles owned by the caller, created with timing enabled; each pair both set or both NULL; four NULLs switch
+ * the hook off).  No synchronisation, nothing else changes: bench.py times the two blend kernels INSIDE its timed region
+ * with it (an mgs_timing struct synchronises per call, and a device that idles between kernels clocks the issue-bound
+ * blend kernels ~8 % slower than back-to-back steps do).  Process-wide, not thread-safe, not for use under stream capture. */
+int mgs_debug_set_blend_events(void* fwd_start, void* fwd_end, void* bwd_start, void* bwd_end);
+
 /* Diagnostic (not on the hot path): counts what the blend backward of the matching forward does, into
  * stats_dev[8] (device uint64): [0] 64-instance steps walked, [1] instances that pass the per-quadrant cull and are
  * fetched ("survivors"), [2] survivors with >= 1 active pixel (= wave reductions = atomic instructions),

@@ -62,6 +62,7 @@ SIGNATURES = {
     "mgs_backward_tau": (C.c_void_p, [C.c_void_p, C.c_int32]),
     "mgs_debug_blend_stats": (C.c_int, [C.POINTER(MgsCamera), C.c_int32, C.c_uint64] + [C.c_void_p] * 5),
     "mgs_debug_valu_ceiling": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
+    "mgs_debug_set_blend_events": (C.c_int, [C.c_void_p] * 4),
     "mgs_mark_visible": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mgs_loss_scratch_bytes": (C.c_size_t, []),
     "mgs_loss_forward": (C.c_int, [C.c_int32] * 4 + [C.c_float] + [C.c_void_p] * 9 + [C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -120,6 +120,9 @@ static int check_cam(const mgs_camera* cam) {
 }
 
 // the blend backward forms `index * 64 + slot` in 32 bits (blend.hip, bt_flush): refuse maps it cannot address
+// mgs_debug_set_blend_events: recorded around the blend forward / backward launch of every call while set
+static hipEvent_t g_dbg_fwd_events[2] = {nullptr, nullptr}, g_dbg_bwd_events[2] = {nullptr, nullptr};
+
 static int check_map_size(int32_t P) {
     if (P > MGS_MAX_GAUSSIANS) {
         set_error("P exceeds MGS_MAX_GAUSSIANS (2^26 - 1): the gradient-line offset of the blend backward is 32-bit");
@@ -242,8 +245,10 @@ static int forward_render_impl(const mgs_camera* cam, int32_t P, uint64_t R, boo
     // (the sort's final pass writes the per-tile ranges: no ranges launch since round 4)
     if (int rc = launch_sort(g, b, R, tile_bits(W, H), s, n_dev, (cam->flags & MGS_FLAG_EXCLUSIVE_DEVICE) != 0, img.ranges)) return rc;
     tm.mark();
+    if (g_dbg_fwd_events[0]) MGS_HIP(hipEventRecord(g_dbg_fwd_events[0], s));
     if (int rc = launch_blend_forward(*cam, g, b, img, out_color, out_depth, out_opacity, n_touched,
                                       R > 0 ? radix_error_flag(b.sort_temp, R, tile_bits(W, H)) : nullptr, overflow, s)) return rc;
+    if (g_dbg_fwd_events[1]) MGS_HIP(hipEventRecord(g_dbg_fwd_events[1], s));
     tm.mark();
     if (timing) {
         tm.sync();
@@ -323,7 +328,9 @@ int mgs_backward(const mgs_camera* cam, int32_t P, uint64_t R, const float* mean
     if (R > 0) {
         // colours / opacities take no gradient and do not feed the geometry (no SH): the lighter blend backward
         const bool pose_only = !dL_dcolors && !dL_dopacity && !dL_dsh && !shs;
+        if (g_dbg_bwd_events[0]) MGS_HIP(hipEventRecord(g_dbg_bwd_events[0], s));
         if (int rc = launch_blend_backward(*cam, g, b, img, dL_dcolor, dL_ddepth, grad_acc, pose_only, s)) return rc;
+        if (g_dbg_bwd_events[1]) MGS_HIP(hipEventRecord(g_dbg_bwd_events[1], s));
     }
     tm.mark();
     GeomBackwardArgs a;
@@ -363,6 +370,16 @@ int mgs_debug_valu_ceiling(float* out, int32_t iters, void* stream) {
 }
 
 int mgs_debug_set_radix_spin_limit(uint32_t limit) { return set_radix_spin_limit(limit); }
+
+int mgs_debug_set_blend_events(void* fwd_start, void* fwd_end, void* bwd_start, void* bwd_end) {
+    if ((fwd_start == nullptr) != (fwd_end == nullptr) || (bwd_start == nullptr) != (bwd_end == nullptr)) {
+        set_error("mgs_debug_set_blend_events: a pair is both events or neither");
+        return 1;
+    }
+    g_dbg_fwd_events[0] = (hipEvent_t)fwd_start; g_dbg_fwd_events[1] = (hipEvent_t)fwd_end;
+    g_dbg_bwd_events[0] = (hipEvent_t)bwd_start; g_dbg_bwd_events[1] = (hipEvent_t)bwd_end;
+    return 0;
+}
 
 static int g_opt_debug_sort_exclusive = 0;   // mgs_debug_set_option("debug_sort_exclusive", 1): mgs_debug_sort_pairs sorts as under
                                              // MGS_FLAG_EXCLUSIVE_DEVICE (block ids as tile ids)

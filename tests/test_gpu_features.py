@@ -486,6 +486,43 @@ def test_ticket_and_block_id_tile_ids_agree(native_lib, n, intr):
     assert torch.equal(out[False]["cap"], out[True]["cap"]) and torch.equal(out[False]["cap"], out[False]["color"])
 
 
+def test_blend_event_hook_times_the_two_blend_kernels(native_lib):
+    """mgs_debug_set_blend_events: the library records the caller's events right around the blend-forward and blend-backward
+    launches (what bench.py times the dominant kernel with inside its timed region) -- no sync, results unchanged, and
+    nothing is recorded once the hook is off again."""
+    from monogs_amd._lib import check
+    from monogs_amd.rasterizer import GaussianRasterizer
+    sc = make_scene(20000, "fr3_office", seed=4)
+    st = _hip_st(sc)
+    dev = lambda t: t.to(DEV)  # noqa: E731
+
+    def run():
+        xyz = dev(sc.means3D).requires_grad_(True)
+        out = GaussianRasterizer(st)(means3D=xyz, means2D=torch.zeros(20000, 3, device=DEV), opacities=dev(sc.opacities),
+                                     colors_precomp=dev(sc.colors), scales=dev(sc.scales), rotations=dev(sc.rotations))
+        torch.autograd.backward([out[0], out[2]], [dev(sc.grad_color), dev(sc.grad_depth)])
+        return out[0].detach().clone(), xyz.grad.clone()
+
+    ref = run()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    for e in ev:
+        e.record()
+    torch.cuda.synchronize()
+    assert native_lib.mgs_debug_set_blend_events(ev[0].cuda_event, None, None, None) == 1        # half a pair
+    check(native_lib.mgs_debug_set_blend_events(*[e.cuda_event for e in ev]), "mgs_debug_set_blend_events")
+    try:
+        got = run()
+    finally:
+        check(native_lib.mgs_debug_set_blend_events(None, None, None, None), "mgs_debug_set_blend_events")
+    torch.cuda.synchronize()
+    t_f, t_b = ev[0].elapsed_time(ev[1]), ev[2].elapsed_time(ev[3])
+    assert 0.001 < t_f < 5.0 and 0.001 < t_b < 5.0, (t_f, t_b)
+    assert torch.equal(got[0], ref[0])
+    run()                                            # hook off: the events keep their times
+    torch.cuda.synchronize()
+    assert ev[0].elapsed_time(ev[1]) == t_f and ev[2].elapsed_time(ev[3]) == t_b
+
+
 def test_exact_status_words_of_other_streams_wait_for_check_overflow(native_lib):
     """The exact path hands the previous forward's status word to the next forward's count read-back only when both ran on the
     same stream of the same device (the read-back is ordered behind that stream's kernels only); a word written on another

@@ -410,7 +410,9 @@ def eager_tracking_probe(frames, intr, gmap, bg, iters: int, profile_flavour=Non
                         vp.retract()
                     elif name == "fused_pose_step":
                         popt.step_and_retract()
-            for _ in range(10):
+            # (un-timed iterations first, enough of them for the device to settle in the power state this loop keeps it in:
+            #  behind a host-bound flavour it idles most of the time, and the first ~40 ms of load after that run slow)
+            for _ in range(max(10, iters // 2)):
                 it()
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -444,7 +446,7 @@ def eager_tracking_probe(frames, intr, gmap, bg, iters: int, profile_flavour=Non
             fused_losses.get_loss_tracking(pkg["render"], pkg["depth"], pkg["opacity"], vp).backward()
             for t in leaves:
                 t.grad = None
-        for _ in range(10):
+        for _ in range(max(10, iters // 2)):
             it_dev()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -324,6 +324,11 @@ __global__ void __launch_bounds__(RS_THREADS * TPW) rs_tile_hist_kernel(RsTileHi
     if (a.only_if_wide && a.wide[0] == 0u) return;
     RS_HSTAMP(0);
     const uint32_t n_live = a.n_dev ? min(a.n, a.n_dev[0]) : a.n;
+    // capacity mode launches tiles for the capacity (1.5 x the live count by default).  A workgroup whose tiles are all
+    // dead has nothing to write: nobody reads the count row of a dead tile (a tile adds up rows of EARLIER siblings only),
+    // and the tree rows it would add zeros to were cleared with the sort's scratch.  (With a single level -- at most 8 tiles,
+    // never the case on this path -- the count rows ARE the top level, which is read in full.)
+    if (a.tr.levels > 1 && (uint64_t)blockIdx.x * TPW * TILE_PAIRS >= n_live) return;
     const uint32_t tile = blockIdx.x * TPW + q, tile_start = tile * TILE_PAIRS;
     const uint32_t tile_n = tile_start < n_live ? min(TILE_PAIRS, n_live - tile_start) : 0u;     // 0: dead (capacity mode) or past the end
     uint32_t k[ITEMS];

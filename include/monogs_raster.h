@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define MGS_ABI_VERSION 8
+#define MGS_ABI_VERSION 9
 #define MGS_TILE 16 /* tile edge in pixels; ranges are per 16x16 tile */
 
 /* GaussianRasterizationSettings, minus `prefiltered` / `debug` which are call flags
@@ -235,11 +235,17 @@ int mgs_debug_valu_ceiling(float* out, int32_t iters, void* stream);
 int mgs_debug_set_blend_events(void* fwd_start, void* fwd_end, void* bwd_start, void* bwd_end);
 
 /* Diagnostic (not on the hot path): counts what the blend backward of the matching forward does, into
- * stats_dev[8] (device uint64): [0] 64-instance steps walked, [1] instances that pass the per-quadrant cull and are
- * fetched ("survivors"), [2] survivors with >= 1 active pixel (= wave reductions = atomic instructions),
+ * stats_dev[MGS_BLEND_STATS_WORDS] (device uint64): [0] 64-instance steps walked, [1] instances that pass the per-quadrant
+ * cull and are fetched ("survivors"), [2] survivors with >= 1 active pixel (= wave reductions = atomic instructions),
  * [3] active (pixel, instance) pairs, [4] inactive survivors that are inactive only because of the depth order,
  * [5..7] active survivors with <= 2 / 4 / 8 active pixels.  bench.py divides the kernel's VALU instruction count
- * (rocprofv3 --pmc) by [1] and [2] to report instructions per survivor. */
+ * (rocprofv3 --pmc) by [1] and [2] to report instructions per survivor.
+ * [8 + 3 d + {0, 1, 2}], d = 0..4 (round 5): what the walk would cost if the wave ran one survivor stream per GROUP of
+ * pixels -- d = 0: two 8x4 halves (top / bottom), 1: two 4x8 halves (left / right), 2: four 4x4 blocks, 3: four 8x2 strips,
+ * 4: eight 4x2 blocks -- with the cull run per group: {0} loop trips when the groups' survivor lists are paired step by step
+ * (sum over steps of the longest group list), {1} (group, survivor) rows, {2} trips when every group runs down its own
+ * list over the whole walk (sum over quadrant walks of the longest group total).  Compare with [1]. */
+#define MGS_BLEND_STATS_WORDS 24
 int mgs_debug_blend_stats(const mgs_camera* cam, int32_t P, uint64_t num_rendered, const void* geometry,
                           const void* binning, const void* image, uint64_t* stats_dev, void* stream);
 

@@ -11,7 +11,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MGS_LIB_PATH") or os.path.join(_HERE, "lib", "libmonogs_raster.so")   # (override: kernel experiments)
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 c_float_p = C.c_void_p   # device pointers travel as integers (tensor.data_ptr())
 

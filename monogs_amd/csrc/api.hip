@@ -355,7 +355,7 @@ int mgs_debug_blend_stats(const mgs_camera* cam, int32_t P, uint64_t R, const vo
     if (check_cam(cam)) return 1;
     if (!geometry || !image || !stats_dev || (R > 0 && !binning)) { set_error("bad arguments"); return 1; }
     hipStream_t s = (hipStream_t)stream;
-    MGS_HIP(zero_fill(stats_dev, 8 * sizeof(uint64_t), s));
+    MGS_HIP(zero_fill(stats_dev, MGS_BLEND_STATS_WORDS * sizeof(uint64_t), s));
     if (P == 0 || R == 0) return 0;
     const int W = cam->image_width, H = cam->image_height;
     GeometryState g = GeometryState::carve(const_cast<void*>(geometry), P);

@@ -846,12 +846,108 @@ __global__ void __launch_bounds__(256) blend_backward_stats_kernel(BlendArgs a, 
     }
 }
 
+// ---- diagnostic, round 5: how many loop trips would the walk take if the wave ran SEVERAL survivor streams side by side,
+// one per group of pixels?  39 of a survivor's 64 lanes are active on average (stats[3] / stats[2]) and narrowing EXEC saves
+// no time on gfx950, so the only way to use the idle lanes is to give them another survivor.  For five ways of cutting the
+// 8x8 quadrant into groups (two 8x4 halves, two 4x8 halves, four 4x4 blocks, four 8x2 strips, eight 4x2 blocks) the cull is
+// run per group (the same box + ellipse test against the group's rectangle and its alive pixels) and three sums are kept:
+//   [8 + 3 d + 0]  sum over steps of max_g S_g      trips when the groups' lists are paired step by step
+//   [8 + 3 d + 1]  sum over steps of sum_g S_g      (group, survivor) rows: what the backward would have to flush
+//   [8 + 3 d + 2]  sum over walks of max_g sum_steps S_g   trips when every group runs down a list of its own
+// to be read against stats[1] (survivors of the whole-quadrant cull = trips now).
+__device__ __forceinline__ bool rect_hit(const float4 c, const float4 n, float qx0, float qy0, int ox, int oy, int w, int h,
+                                         unsigned long long alive) {
+    if (c.z < 0.f) return false;
+    const float x0q = qx0 - 0.05f - c.x, y0q = qy0 - 0.05f - c.y;                      // quadrant origin relative to the centre
+    const float x0 = x0q + (float)ox, x1 = qx0 + (float)(ox + w - 1) + 0.05f - c.x;   // the group's rectangle
+    const float y0 = y0q + (float)oy, y1 = qy0 + (float)(oy + h - 1) + 0.05f - c.y;
+    if (!((c.z >= x0) && (-c.z <= x1) && (c.w >= y0) && (-c.w <= y1))) return false;
+    {
+        const int ix0 = (int)fminf(8.f, fmaxf(0.f, ceilf(-x0q - c.z - 0.06f))), ix1 = (int)fminf(7.f, fmaxf(-1.f, floorf(-x0q + c.z + 0.06f)));
+        const int iy0 = (int)fminf(8.f, fmaxf(0.f, ceilf(-y0q - c.w - 0.06f))), iy1 = (int)fminf(7.f, fmaxf(-1.f, floorf(-y0q + c.w + 0.06f)));
+        if (ix0 > ix1 || iy0 > iy1) return false;
+        const unsigned long long cols = (unsigned long long)((0xFFu >> (7 - ix1)) & (0xFFu << ix0) & 0xFFu) * 0x0101010101010101ull;
+        const unsigned long long rows = (~0ull >> (8 * (7 - iy1))) & (~0ull << (8 * iy0));
+        const unsigned long long gcols = (unsigned long long)(((1u << w) - 1u) << ox) * 0x0101010101010101ull;
+        const unsigned long long grows = ((h >= 8 ? ~0ull : ((1ull << (8 * h)) - 1ull)) << (8 * oy));
+        if ((cols & rows & gcols & grows & alive) == 0ull) return false;
+    }
+    if (x0 <= 0.f && x1 >= 0.f && y0 <= 0.f && y1 >= 0.f) return true;
+    if (!(n.x > 0.f) || !(n.z > 0.f)) return true;
+    const float rby = -n.y * __builtin_amdgcn_rcpf(n.z), rbx = -n.y * __builtin_amdgcn_rcpf(n.x);
+    auto edge_x = [&](float xe) { const float t = fminf(y1, fmaxf(y0, rby * xe)); return n.x * xe * xe + 2.f * n.y * xe * t + n.z * t * t; };
+    auto edge_y = [&](float ye) { const float t = fminf(x1, fmaxf(x0, rbx * ye)); return n.x * t * t + 2.f * n.y * t * ye + n.z * ye * ye; };
+    return fminf(fminf(edge_x(x0), edge_x(x1)), fminf(edge_y(y0), edge_y(y1))) <= 1.02f;
+}
+__global__ void __launch_bounds__(256) blend_group_stats_kernel(BlendArgs a, int ntiles, const uint32_t* __restrict__ n_contrib,
+                                                                unsigned long long* __restrict__ stats) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tile = (int)blockIdx.x;
+    if (tile >= ntiles) return;
+    const int tx = tile % a.gx, ty = tile / a.gx;
+    const uint2 range = a.ranges[tile];
+    if (range.y <= range.x) return;
+    const int qx0i = tx * TILE + (wave & 1) * SUB, qy0i = ty * TILE + (wave >> 1) * SUB;
+    const int pxi = qx0i + (lane & 7), pyi = qy0i + (lane >> 3);
+    const bool inside = pxi < a.W && pyi < a.H;
+    const float qx0 = (float)qx0i, qy0 = (float)qy0i;
+    const uint32_t last = inside ? n_contrib[(size_t)pyi * a.W + pxi] : 0u;
+    const uint32_t maxc = wave_max_u32(last);
+    if (maxc == 0) return;
+    const uint32_t end = range.x + maxc;
+    // decomposition d: NG[d] groups of GW[d] x GH[d] pixels, GX[d] groups per row of groups
+    constexpr int ND = 5;
+    constexpr int NG[ND] = {2, 2, 4, 4, 8}, GW[ND] = {8, 4, 4, 8, 4}, GH[ND] = {4, 8, 4, 2, 2}, GX[ND] = {1, 2, 2, 1, 2};
+    unsigned long long trips_step[ND] = {0, 0, 0, 0, 0}, rows[ND] = {0, 0, 0, 0, 0};
+    uint32_t walk[ND][8];
+#pragma unroll
+    for (int d = 0; d < ND; ++d)
+#pragma unroll
+        for (int g = 0; g < 8; ++g) walk[d][g] = 0;
+    for (int b = (int)((maxc - 1) / WAVE); b >= 0; --b) {
+        const uint32_t i = range.x + (uint32_t)b * WAVE + lane;
+        float4 box = make_float4(0.f, 0.f, -1.f, -1.f), el = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < end) {
+            const uint32_t gid_l = a.point_list[i];
+            box = a.rec[(size_t)gid_l * 4];
+            el = a.rec[(size_t)gid_l * 4 + 3];
+        }
+        const unsigned long long alive = __builtin_amdgcn_ballot_w64(last >= (uint32_t)b * WAVE + 1u);
+#pragma unroll
+        for (int d = 0; d < ND; ++d) {
+            int mx = 0, sum = 0;
+#pragma unroll
+            for (int g = 0; g < NG[d]; ++g) {
+                const int ox = (g % GX[d]) * GW[d], oy = (g / GX[d]) * GH[d];
+                const int n = __popcll(__builtin_amdgcn_ballot_w64(rect_hit(box, el, qx0, qy0, ox, oy, GW[d], GH[d], alive)));
+                mx = max(mx, n);
+                sum += n;
+                walk[d][g] += (uint32_t)n;
+            }
+            trips_step[d] += mx;
+            rows[d] += sum;
+        }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int d = 0; d < ND; ++d) {
+            uint32_t mx = 0;
+#pragma unroll
+            for (int g = 0; g < NG[d]; ++g) mx = max(mx, walk[d][g]);
+            atomicAdd(stats + 8 + 3 * d + 0, trips_step[d]);
+            atomicAdd(stats + 8 + 3 * d + 1, rows[d]);
+            atomicAdd(stats + 8 + 3 * d + 2, (unsigned long long)mx);
+        }
+    }
+}
+
 int launch_blend_backward_stats(const mgs_camera& cam, const GeometryState& g, const BinningState& b,
                                 const ImageState& img, unsigned long long* stats, hipStream_t s) {
     const BlendArgs a = make_args(cam, g, b, img);
     const int ntiles = a.gx * tiles_y(a.H);
     if (ntiles == 0) return 0;
     hipLaunchKernelGGL(blend_backward_stats_kernel, dim3(ntiles), dim3(256), 0, s, a, ntiles, img.n_contrib, stats);
+    hipLaunchKernelGGL(blend_group_stats_kernel, dim3(ntiles), dim3(256), 0, s, a, ntiles, img.n_contrib, stats);
     MGS_HIP(hipGetLastError());
     return 0;
 }

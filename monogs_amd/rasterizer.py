@@ -418,15 +418,18 @@ def debug_blend_stats(color: torch.Tensor) -> dict:
     lib = _lib.load()
     means3D, _, _, _, _, _, _, _, arena, binning = fn.saved_tensors
     cam = fn.cam
-    out = torch.zeros(8, dtype=torch.int64, device=means3D.device)
+    out = torch.zeros(24, dtype=torch.int64, device=means3D.device)      # MGS_BLEND_STATS_WORDS
     with _device_guard(means3D.device):
         _lib.check(lib.mgs_debug_blend_stats(C.byref(cam), means3D.shape[0], fn.num_rendered,
                                              arena.data_ptr() + fn.geom_off, binning.data_ptr(),
                                              arena.data_ptr() + fn.img_off, out.data_ptr(), _stream()),
                    "mgs_debug_blend_stats")
     v = out.tolist()
+    groups = {}
+    for d, name in enumerate(("halves_8x4", "halves_4x8", "blocks_4x4", "strips_8x2", "blocks_4x2")):
+        groups[name] = dict(trips_paired_per_step=v[8 + 3 * d], rows=v[9 + 3 * d], trips_own_lists=v[10 + 3 * d])
     return dict(steps=v[0], survivors=v[1], active_survivors=v[2], active_pairs=v[3], inactive_by_depth_order=v[4],
-                active_le2=v[5], active_le4=v[6], active_le8=v[7])
+                active_le2=v[5], active_le4=v[6], active_le8=v[7], group_streams=groups)
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,

@@ -104,7 +104,11 @@ __device__ __forceinline__ Rec fetch(const BlendArgs& a, uint32_t gid_uniform) {
 //     EXEC = all
 // One asm block (the compiler must never see a narrowed EXEC): 17 scalar + 23 vector instructions per survivor, 19 + 25
 // while a pixel of the quadrant is still in front of half its light (TOUCH: only then can T (1 - alpha) exceed 0.5).
+#ifdef MGS_FWD_SCALAR
+#define MGS_RECOP "s"          // experiment: the survivor's record through two scalar loads (SGPR offset), as the round-5 backward
+#else
 #define MGS_RECOP "v"          // the survivor's record comes back from the per-wave LDS queue in vector registers
+#endif
 template <bool TOUCH>
 __device__ __forceinline__ void blend_one(unsigned long long& live, unsigned long long& mask, float& T, uint32_t& last, float& C0, float& C1, float& C2,
                                       float& D, const Rec& g, float power, float alpha, uint32_t pos, int j,
@@ -213,6 +217,49 @@ __global__ void __launch_bounds__(256) blend_forward_kernel(BlendArgs a, float* 
     // went to L2) and five scalar instructions of address arithmetic: 0.215 -> 0.191 ms at C5, 38.0 -> 34.8 us at 100 k / VGA.
     // (Rounds 2 built the same queue against the mask-algebra kernel and measured no gain: that kernel was bound by its
     // scalar ALU work, not by the fetch.)  No barrier: the queue belongs to one wave and a wave's LDS operations run in order.
+#ifdef MGS_FWD_SCALAR
+    typedef float fv2 __attribute__((ext_vector_type(2)));
+    typedef float fv8 __attribute__((ext_vector_type(8)));
+    const const_float_p recs = MGS_CONST(reinterpret_cast<const float*>(a.rec));
+    auto prefetch = [&](uint32_t i) {
+        gid_n = 0;
+        box_n = make_float4(0.f, 0.f, -1.f, -1.f);
+        if (i < range.y) {
+            gid_n = a.point_list[i];
+            box_n = a.rec[(size_t)gid_n * 4];
+            ell_n = a.rec[(size_t)gid_n * 4 + 3];
+        }
+    };
+    auto walk_step = [&](auto touch_tag, uint32_t base, uint32_t gid_l, unsigned long long mask) {
+        int touched_cnt = 0;
+        const uint32_t goff_l = gid_l << 6;
+        while (mask) {
+            int j;
+            asm volatile("s_ff1_i32_b64 %0, %1\n\ts_bitset0_b64 %1, %0" : "=&s"(j), "+s"(mask));
+            const uint32_t goff = (uint32_t)__builtin_amdgcn_readlane((int)goff_l, j);
+            fv2 r0;
+            fv8 r1;
+            asm volatile("s_load_dwordx2 %0, %2, %3\n\ts_load_dwordx8 %1, %2, %3 offset:0x10\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&s"(r0), "=&s"(r1) : "s"(recs), "s"(goff) : "memory");
+            const Rec g{r0[0], r0[1], r1[0], r1[1], r1[2], r1[3], r1[4], r1[5], r1[6], r1[7]};
+            const float dx = g.px - pxf, dy = g.py - pyf;
+            const float power = dx * (g.ca * dx + g.cb * dy) + (g.cc * dy) * dy;
+            const float alpha = fminf(0.99f, g.op * __builtin_amdgcn_exp2f(power));
+            blend_one<decltype(touch_tag)::value>(live, mask, T, last, C0, C1, C2, D, g, power, alpha,
+                                                  (base - range.x) + (uint32_t)j + 1u, j, touched_cnt);
+        }
+        if (decltype(touch_tag)::value && touched_cnt != 0) atomicAdd(n_touched + gid_l, touched_cnt);
+    };
+    if (range.x < range.y) prefetch(range.x + lane);
+    for (uint32_t base = range.x; base < range.y && live != 0ull; base += WAVE) {
+        const uint32_t gid_l = gid_n;
+        const float4 c = box_n, el = ell_n;
+        prefetch(base + WAVE + lane);
+        const unsigned long long mask = __builtin_amdgcn_ballot_w64(quadrant_hit(c, el, qx0, qy0, live));
+        if ((live & __builtin_amdgcn_ballot_w64(T > 0.5f)) != 0ull) walk_step(std::true_type{}, base, gid_l, mask);
+        else walk_step(std::false_type{}, base, gid_l, mask);
+    }
+#else
     __shared__ __attribute__((aligned(16))) float4 s_queue[4][WAVE][3];
     float4 c1_n = make_float4(0.f, 0.f, 0.f, 0.f), c2_n = c1_n;
     float4* const my_entry = &s_queue[wave][lane][0];
@@ -263,6 +310,7 @@ __global__ void __launch_bounds__(256) blend_forward_kernel(BlendArgs a, float* 
         if ((live & __builtin_amdgcn_ballot_w64(T > 0.5f)) != 0ull) walk_step(std::true_type{}, base, gid_l, mask);
         else walk_step(std::false_type{}, base, gid_l, mask);
     }
+#endif
     if (inside) {
         const size_t pix = (size_t)pyi * a.W + pxi, HW = (size_t)a.H * a.W;
         final_T[pix] = T;
@@ -611,8 +659,9 @@ struct BtLane {
     uint32_t slot_bytes;
     unsigned long long m_out, m_q0, m_q1;
     float* grad_acc;
+    int qxi = 0, qyi = 0;           // the same origin as integers (WIDE_META flush)
 };
-template <bool POSE_ONLY>
+template <bool POSE_ONLY, bool WIDE_META = false>     // WIDE_META: metadata records 256 bytes apart, holding index << 6 (blend_backward_s_kernel)
 __device__ __forceinline__ void bt_flush(const BtLane L, int n) {
     // Everything a lane derives from its number here (row, q, three LDS addresses, its first pixel) is RE-derived per batch,
     // ~8 VALU per four survivors: hoisted out of the walk by the compiler these values cost six more VGPRs over the whole
@@ -622,11 +671,18 @@ __device__ __forceinline__ void bt_flush(const BtLane L, int n) {
     const int q = lane & 15, row = lane >> 4;
     const float4 h4 = *reinterpret_cast<const float4*>(L.fac + 4 * lane);                   // [row][4 q .. 4 q + 3]
     const float4 w4 = *reinterpret_cast<const float4*>(L.fac + BT_SLOTS * WAVE + 4 * lane);
-    const BtMetaRec me = L.meta[row];
+    const BtMetaRec me = L.meta[WIDE_META ? row * 16 : row];
     // [channel][q][4]: the sixteen lanes of a row read 256 contiguous bytes per channel (conflict-free; laid out [q][channel]
     // the 64-byte lane stride put four lanes on every bank: 48 M conflict cycles per launch at C5, r03 PMC)
     const float* const fp = L.pix + q * 4;
-    const float u0 = L.qx0 + (float)(4 * (q & 1)), v0 = L.qy0 + (float)(q >> 1);
+    float u0, v0;
+    if (WIDE_META) {                    // the origin stays in scalar INTEGER registers (see blend_backward_s_kernel); same values
+        int oqx = L.qxi, oqy = L.qyi;
+        asm volatile("" : "+s"(oqx), "+s"(oqy));
+        u0 = (float)(oqx + 4 * (q & 1)), v0 = (float)(oqy + (q >> 1));
+    } else {
+        u0 = L.qx0 + (float)(4 * (q & 1)), v0 = L.qy0 + (float)(q >> 1);
+    }
     const float dy = me.y - v0;
     const float dx0 = me.x - u0, dx1 = dx0 - 1.f, dx2 = dx0 - 2.f, dx3 = dx0 - 3.f;
     const float hx0 = h4.x * dx0, hx1 = h4.y * dx1, hx2 = h4.z * dx2, hx3 = h4.w * dx3;
@@ -650,7 +706,7 @@ __device__ __forceinline__ void bt_flush(const BtLane L, int n) {
     }
     // rows >= n hold a stale slot: masked out.  One instruction, <= 40 active lanes, one 64-byte request per gradient line.
     const unsigned long long rows = n >= BT_SLOTS ? ~0ull : ((1ull << (16 * n)) - 1ull);
-    const uint32_t off = me.g * (uint32_t)(GRAD_FLOATS * sizeof(float)) + L.slot_bytes;
+    const uint32_t off = (WIDE_META ? me.g : me.g * (uint32_t)(GRAD_FLOATS * sizeof(float))) + L.slot_bytes;
     if (__builtin_amdgcn_inverse_ballot_w64(L.m_out & rows))
         asm volatile("global_atomic_add_f32 %0, %1, %2" ::"v"(off), "v"(m), "s"(L.grad_acc) : "memory");
 }
@@ -777,6 +833,215 @@ __global__ void __launch_bounds__(256) blend_backward_t_kernel(BlendArgs a, int 
         }
     }
     if (k) bt_flush<POSE_ONLY>(bl, k);
+}
+
+// =================================================================================================
+// backward, round 5: the transposed accumulation of round 3 with its scalar side cut down and its per-pixel side under EXEC.
+//
+// What round 3 / 4 left per survivor in front of the flush: 31 vector and ~27 scalar-pipe instructions (s_flbit + s_xor for
+// the next mask bit, v_readlane of the index, two 64-bit shifts, a 64-bit add, three s_load in two round trips, two waits,
+// the mask algebra of the activity test, a saveexec for the one-lane metadata store, address arithmetic for it, the batch
+// counter).  tools/ubench/valu_rate.hip (round 5 rows) prices the scalar pipe: a compute unit has ONE scalar ALU for its four
+// SIMDs -- 2.2 ns of SIMD time per scalar instruction alone, ~0.65 ns when it rides behind vector work; kernel time
+// ~= V + 0.3 S reproduces the measured 90 ns per survivor from 75 ns of vector and 48 ns of scalar issue.  (The forward's answer
+// -- records through a per-wave LDS queue -- was built for this kernel too, compacted to 32 entries so that eight workgroups
+// per compute unit stay: 0.383 against 0.339 ms at C5.  The slab and the flush already keep the CU's LDS pipe busy, three
+// broadcast ds_read_b128 per survivor from four SIMDs are another 48 LDS cycles per survivor slot)
+// So the record stays in scalar registers and everything around it goes:
+//   * lane l holds instance 63 - l of the step: walking the step back to front is walking the mask from bit 0, `s_ff1` gives
+//     the lane, `s_bitset0` clears it (2 scalar instructions instead of 5);
+//   * the lane keeps index << 6 -- byte offset of the 64-byte record AND of the gradient line -- so the one v_readlane yields
+//     the SGPR offset of two scalar loads {px, py}, {conic, opacity, colour, depth} off one base: one round trip, no address
+//     arithmetic;
+//   * "list position <= last contributor" is `lane >= 63 - (last - k_first)` against a per-step register; the three activity
+//     tests narrow EXEC (v_cmpx) inside ONE asm block, state updates and factors are plain instructions under it (no v_cndmask,
+//     no mask algebra), the slab slot is cleared by an LDS store under the full EXEC first (a wave's LDS operations run in
+//     order), the batch slot advances only if a pixel was active (s_cselect on EXEC != 0), and lane j stores the slot's
+//     metadata under EXEC = 1 << j.
+// 29 vector + ~16 scalar-pipe instructions per survivor in front of the flush.  Same arithmetic in the same order as
+// blend_backward_t_kernel (the A/B partner, option 1): gradients equal to the last bit of every sum's order.
+// =================================================================================================
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v3f __attribute__((ext_vector_type(3)));
+typedef float v8f __attribute__((ext_vector_type(8)));
+template <bool POSE_ONLY>
+__global__ void __launch_bounds__(256) blend_backward_s_kernel(BlendArgs a, int ntiles,
+                                                               const float* __restrict__ final_T,
+                                                               const uint32_t* __restrict__ n_contrib,
+                                                               const float* __restrict__ dL_dcolor,
+                                                               const float* __restrict__ dL_ddepth,
+                                                               float* __restrict__ grad_acc) {
+    // per wave: the factor slab [h | w][slot][pixel] (2 KB), then the slots' metadata {cx, cy, index << 6}, 256 bytes apart like
+    // the slots themselves: ONE scalar (slab base + open slot x 256) addresses both
+    struct WaveLds { float fac[2][BT_SLOTS][WAVE]; BtMetaRec meta[BT_SLOTS][16]; };
+    __shared__ __attribute__((aligned(16))) WaveLds s_w[4];
+    __shared__ __attribute__((aligned(16))) float s_pix[4][POSE_ONLY ? 1 : 4][16][4];    // [wave][(rgb,) depth][q][4 pixels]
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int tile = (int)blockIdx.x;
+    if (tile >= ntiles) return;
+    const int tx = tile % a.gx, ty = tile / a.gx;
+    const uint2 range = a.ranges[tile];
+    if (range.y <= range.x) return;
+    const size_t HW = (size_t)a.H * a.W;
+    const float bg0 = a.bg[0], bg1 = a.bg[1], bg2 = a.bg[2];
+
+    const int qx0i = tx * TILE + (wave & 1) * SUB, qy0i = ty * TILE + (wave >> 1) * SUB;
+    const int pxi = qx0i + (lane & 7), pyi = qy0i + (lane >> 3);
+    const bool inside = pxi < a.W && pyi < a.H;
+    const size_t pix = (size_t)pyi * a.W + pxi;
+    const float pxf = (float)pxi, pyf = (float)pyi;
+    const float T_final = inside ? final_T[pix] : 0.f;
+    const uint32_t last = inside ? n_contrib[pix] : 0u;
+    const float g0 = inside ? dL_dcolor[pix] : 0.f;
+    const float g1 = inside ? dL_dcolor[HW + pix] : 0.f;
+    const float g2 = inside ? dL_dcolor[2 * HW + pix] : 0.f;
+    const float gd = inside ? dL_ddepth[pix] : 0.f;
+    const float bgT = -T_final * (bg0 * g0 + bg1 * g1 + bg2 * g2);
+    float T = T_final, Bk = 0.f;
+    const uint32_t maxc = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max_u32(last));
+    if (maxc == 0) return;
+    const uint32_t end = range.x + maxc;
+
+    const int q = lane & 15;
+    const int fxi = qx0i + 4 * (q & 1), fyi = qy0i + (q >> 1);
+    if (lane < 16) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool in_i = (fxi + i) < a.W && fyi < a.H;
+            const size_t px_i = (size_t)fyi * a.W + fxi + i;
+            if (!POSE_ONLY) {
+                s_pix[wave][0][q][i] = in_i ? dL_dcolor[px_i] : 0.f;
+                s_pix[wave][1][q][i] = in_i ? dL_dcolor[HW + px_i] : 0.f;
+                s_pix[wave][2][q][i] = in_i ? dL_dcolor[2 * HW + px_i] : 0.f;
+            }
+            s_pix[wave][POSE_ONLY ? 0 : 3][q][i] = in_i ? dL_ddepth[px_i] : 0.f;
+        }
+    }
+    const int slot = POSE_ONLY ? bt_slot6(q) : bt_slot10(q);
+    const uint32_t slot_bytes = slot < 0 ? 0u : (uint32_t)slot * 4u;
+    const unsigned long long m_out = __builtin_amdgcn_ballot_w64(slot >= 0);
+    const unsigned long long m_q0 = __builtin_amdgcn_ballot_w64((q & 3) == 0), m_q1 = __builtin_amdgcn_ballot_w64((q & 3) == 1);
+    const BtLane bl{&s_w[wave].fac[0][0][0], &s_pix[wave][0][0][0], &s_w[wave].meta[0][0], lane, 0.f, 0.f, slot_bytes, m_out, m_q0, m_q1, grad_acc, qx0i, qy0i};
+    const uint32_t wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)&s_w[threadIdx.x >> 6]);   // LDS address (SGPR)
+    const const_float_p recs = MGS_CONST(reinterpret_cast<const float*>(a.rec));
+    uint32_t koff = 0;              // open batch: survivors x 256 = byte offset of the open slot in the slab and in the metadata (SGPR)
+    float zero = 0.f;
+    asm volatile("" : "+v"(zero));  // (a VGPR holding 0: data operand of the slot-clearing LDS store)
+
+    uint32_t gid_n = 0;
+    float4 box_n = make_float4(0.f, 0.f, -1.f, -1.f), ell_n = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto prefetch = [&](int b) {                    // lane l takes instance 63 - l of step b
+        gid_n = 0;
+        box_n = make_float4(0.f, 0.f, -1.f, -1.f);
+        const uint32_t i = range.x + (uint32_t)b * WAVE + (uint32_t)(63 - lane);
+        if (b >= 0 && i < end) {
+            gid_n = a.point_list[i];
+            box_n = a.rec[(size_t)gid_n * 4];
+            ell_n = a.rec[(size_t)gid_n * 4 + 3];
+        }
+    };
+    prefetch((int)((maxc - 1) / WAVE));
+    for (int b = (int)((maxc - 1) / WAVE); b >= 0; --b) {
+        const float4 c = box_n, el = ell_n;
+        v3f meta = {c.x, c.y, __uint_as_float(gid_n << 6)};        // what the lane notes for the flush if its instance survives
+        prefetch(b - 1);
+        const unsigned long long alive = __builtin_amdgcn_ballot_w64(last >= (uint32_t)b * WAVE + 1u);
+        // (the quadrant origin as floats is re-derived per step from the scalar integers: kept across the walk the two floats
+        //  sit in vector registers, and the kernel has exactly 64)
+        int qxs = qx0i, qys = qy0i;
+        asm volatile("" : "+s"(qxs), "+s"(qys));
+        unsigned long long mask = __builtin_amdgcn_ballot_w64(quadrant_hit(c, el, (float)qxs, (float)qys, alive));
+        // lane j holds the instance with list position k_first + 63 - j: a pixel takes it only if that is <= last,
+        // i.e. j >= 63 + k_first - last
+        const int thr = 63 + (int)((uint32_t)b * WAVE + 1u) - (int)last;
+        // One survivor: pop the next set bit (the lane), fetch its record with two scalar loads off the lane's index << 6.
+        // The fetch of survivor t + 1 is ISSUED before survivor t is evaluated and only waited for one trip later (two
+        // register sets, the loop unrolled by two: no copies).  A scalar load that misses the 16 KB scalar cache takes ~240 ns
+        // (tools/ubench/valu_rate.hip, "s_load_dwordx8 x2 + wait"), a survivor ~60 ns of this wave's own issue: with the wait
+        // right behind the load, eight waves per SIMD are just enough to cover it and six (the average residency) are not.
+        // (Scalar loads return out of order, so the only wait there is is lgkmcnt(0): it sits at the TOP of a trip, before the
+        //  next fetch is issued.)
+#define BS_POP(J, R0, R1)                                                                                                    \
+        asm volatile("s_ff1_i32_b64 %0, %1\n\ts_bitset0_b64 %1, %0" : "=&s"(J), "+s"(mask));                                 \
+        {                                                                                                                    \
+            const uint32_t goff = (uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(meta[2]), J);                     \
+            asm volatile("s_load_dwordx2 %0, %2, %3\n\ts_load_dwordx8 %1, %2, %3 offset:0x10"                                \
+                         : "=&s"(R0), "=&s"(R1) : "s"(recs), "s"(goff) : "memory");                                          \
+        }
+        auto evaluate = [&](const v2f r0, const v8f r1, const int j) {
+                float dx, dy, t1, t2, G, al, inv, qq;
+                uint32_t adv, sa, tmp;
+                asm volatile(
+                    "v_sub_f32_e32 %[dx], %[px], %[pxf]\n\t"
+                    "v_sub_f32_e32 %[dy], %[py], %[pyf]\n\t"
+                    "v_mul_f32_e32 %[t1], %[cb], %[dy]\n\t"
+                    "v_mul_f32_e32 %[t2], %[cc], %[dy]\n\t"
+                    "v_fmac_f32_e32 %[t1], %[ca], %[dx]\n\t"
+                    "v_mul_f32_e32 %[t2], %[dy], %[t2]\n\t"
+                    "v_fmac_f32_e32 %[t2], %[dx], %[t1]\n\t"               // power (log2 of the falloff), as the other kernels form it
+                    "v_exp_f32_e32 %[G], %[t2]\n\t"
+                    "s_add_u32 %[tmp], %[wbase], %[koff]\n\t"               // the open slot
+                    "v_lshl_add_u32 %[sa], %[lane], 2, %[tmp]\n\t"           // this lane's word of it
+                    "ds_write2st64_b32 %[sa], %[zero], %[zero] offset1:4\n\t"   // the slot's h and w of every pixel <- 0 (full EXEC)
+                    "v_cmpx_ge_i32_e32 vcc, %[j], %[thr]\n\t"              // EXEC: pixels whose last contributor is not in front of j
+                    "v_cmpx_nlt_f32_e32 vcc, 0, %[t2]\n\t"                 //       and power <= 0
+                    "v_mul_f32_e32 %[al], %[op], %[G]\n\t"
+                    "v_min_f32_e32 %[al], 0x3f7d70a4, %[al]\n\t"           // min(0.99, opacity G)
+                    "v_cmpx_ngt_f32_e32 vcc, %[amin], %[al]\n\t"           //       and alpha >= 1/255
+                    "v_sub_f32_e32 %[inv], 1.0, %[al]\n\t"
+                    "v_rcp_f32_e32 %[inv], %[inv]\n\t"
+                    "v_mul_f32_e32 %[qq], %[cr], %[g0]\n\t"
+                    "v_fmac_f32_e32 %[qq], %[cg], %[g1]\n\t"
+                    "v_fmac_f32_e32 %[qq], %[cb2], %[g2]\n\t"
+                    "v_fmac_f32_e32 %[qq], %[cz], %[gd]\n\t"
+                    "v_mul_f32_e32 %[T], %[T], %[inv]\n\t"                 // T <- T / (1 - alpha): transmittance in front of j
+                    "v_sub_f32_e32 %[qq], %[qq], %[Bk]\n\t"                // diff
+                    "v_mul_f32_e32 %[dx], %[T], %[qq]\n\t"
+                    "v_fmac_f32_e32 %[dx], %[bgT], %[inv]\n\t"             // dL/dalpha
+                    "v_mul_f32_e32 %[dx], %[G], %[dx]\n\t"                 // h = G dL/dalpha
+                    "v_mul_f32_e32 %[dy], %[al], %[T]\n\t"                 // w = alpha T
+                    "v_fmac_f32_e32 %[Bk], %[al], %[qq]\n\t"               // Bk <- Bk + alpha diff
+                    "ds_write2st64_b32 %[sa], %[dx], %[dy] offset1:4\n\t"  // (active pixels only)
+                    "s_cmp_lg_u64 exec, 0\n\t"
+                    "s_cselect_b32 %[adv], 256, 0\n\t"                     // the slot is taken only if some pixel was active
+                    "s_lshl_b64 exec, 1, %[j]\n\t"                         // lane j: the slot's metadata {centre, index << 6}
+                    "v_mov_b32_e32 %[sa], %[tmp]\n\t"
+                    "ds_write_b96 %[sa], %[meta] offset:2048\n\t"
+                    "s_mov_b64 exec, -1\n\t"
+                    : [dx] "=&v"(dx), [dy] "=&v"(dy), [t1] "=&v"(t1), [t2] "=&v"(t2), [G] "=&v"(G), [al] "=&v"(al), [inv] "=&v"(inv),
+                      [qq] "=&v"(qq), [sa] "=&v"(sa), [T] "+v"(T), [Bk] "+v"(Bk), [adv] "=&s"(adv), [tmp] "=&s"(tmp)
+                    : [px] "s"(r0[0]), [py] "s"(r0[1]), [ca] "s"(r1[0]), [cb] "s"(r1[1]), [cc] "s"(r1[2]), [op] "s"(r1[3]),
+                      [cr] "s"(r1[4]), [cg] "s"(r1[5]), [cb2] "s"(r1[6]), [cz] "s"(r1[7]), [pxf] "v"(pxf), [pyf] "v"(pyf), [thr] "v"(thr),
+                      [j] "s"(j), [g0] "v"(g0), [g1] "v"(g1), [g2] "v"(g2), [gd] "v"(gd), [bgT] "v"(bgT), [lane] "v"(lane), [zero] "v"(zero),
+                      [koff] "s"(koff), [wbase] "s"(wbase), [meta] "v"(meta), [amin] "s"(1.0f / 255.0f)
+                    : "vcc", "scc", "memory");
+                koff += adv;
+            if (koff == BT_SLOTS * 256) {
+                bt_flush<POSE_ONLY, true>(bl, BT_SLOTS);
+                koff = 0;
+            }
+        };
+        if (mask) {
+            int jA, jB = 0;
+            v2f a0, b0;
+            v8f a1, b1;
+            BS_POP(jA, a0, a1)
+            for (;;) {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a0), "+s"(a1) : : "memory");        // record A has arrived
+                const bool moreB = mask != 0ull;
+                if (moreB) { BS_POP(jB, b0, b1) }
+                evaluate(a0, a1, jA);
+                if (!moreB) break;
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(b0), "+s"(b1) : : "memory");        // record B has arrived
+                const bool moreA = mask != 0ull;
+                if (moreA) { BS_POP(jA, a0, a1) }
+                evaluate(b0, b1, jB);
+                if (!moreA) break;
+            }
+        }
+#undef BS_POP
+    }
+    if (koff) bt_flush<POSE_ONLY, true>(bl, (int)(koff >> 8));
 }
 
 // ---- diagnostic: what the backward walk does, counted (not on the hot path; mgs_debug_blend_stats) --------------
@@ -954,14 +1219,21 @@ int launch_blend_backward_stats(const mgs_camera& cam, const GeometryState& g, c
 
 // (The wave-per-tile and half-tile-per-wave variants of round 1 lost at every size and are gone; DESIGN.md section 4
 //  keeps their measurements.)
-int g_opt_blend_bwd_transposed = 1;     // mgs_debug_set_option("blend_bwd_transposed", 0 | 1): 0 = the per-survivor wave reduction
+int g_opt_blend_bwd_transposed = 2;     // mgs_debug_set_option("blend_bwd_transposed", 0 | 1 | 2): 2 = scalar side trimmed + EXEC (round 5), 1 = scalar-fetch transposed (round 3), 0 = the per-survivor wave reduction
 int launch_blend_backward(const mgs_camera& cam, const GeometryState& g, const BinningState& b,
                           const ImageState& img, const float* dL_dcolor, const float* dL_ddepth, float* grad_acc,
                           bool pose_only, hipStream_t s) {
     const BlendArgs a = make_args(cam, g, b, img);
     const int ntiles = a.gx * tiles_y(a.H);
     if (ntiles == 0) return 0;
-    if (g_opt_blend_bwd_transposed != 0) {
+    if (g_opt_blend_bwd_transposed == 2) {
+        if (pose_only)
+            hipLaunchKernelGGL((blend_backward_s_kernel<true>), dim3(ntiles), dim3(256), 0, s, a, ntiles, img.final_T,
+                               img.n_contrib, dL_dcolor, dL_ddepth, grad_acc);
+        else
+            hipLaunchKernelGGL((blend_backward_s_kernel<false>), dim3(ntiles), dim3(256), 0, s, a, ntiles, img.final_T,
+                               img.n_contrib, dL_dcolor, dL_ddepth, grad_acc);
+    } else if (g_opt_blend_bwd_transposed != 0) {
         if (pose_only)
             hipLaunchKernelGGL((blend_backward_t_kernel<true>), dim3(ntiles), dim3(256), 0, s, a, ntiles, img.final_T,
                                img.n_contrib, dL_dcolor, dL_ddepth, grad_acc);

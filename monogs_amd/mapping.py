@@ -91,8 +91,10 @@ class _Plan:
         self.iter_dev = torch.zeros(1, dtype=torch.int32, device=dev)
         # pipelined exchange (WindowMapper.exchange = "per_keyframe"): one gradient bucket per owned keyframe, reduced on
         # its own while the next keyframe renders; `slot_graphs`: one captured (render, loss, backward) per owned keyframe
-        self.pipelined = bool(mapper.sharded and mapper.exchange == "per_keyframe" and len(self.mine) > 1)
-        self.slot_flat = [torch.zeros(P * _GRAD_COLS, **f32) for _ in self.mine] if self.pipelined else []
+        # (decided from rank-INDEPENDENT quantities: every rank issues exactly `rows` slot collectives of the same size, a rank
+        #  that owns fewer keyframes -- any window that is not a multiple of the world size -- contributes zeroed slots)
+        self.pipelined = bool(mapper.sharded and mapper.exchange == "per_keyframe" and self.rows > 1)
+        self.slot_flat = [torch.zeros(P * _GRAD_COLS, **f32) for _ in range(self.rows)] if self.pipelined else []
         self.slot_graphs = None
 
     def grad_view(self, col0: int, cols: int):
@@ -299,7 +301,7 @@ class WindowMapper:
         else:
             p.slot_graphs[0].replay()                                # (the activations)
             produce = lambda j: p.slot_graphs[1 + j].replay()        # noqa: E731
-        W.pipelined_all_reduce(len(p.mine), produce, p.slot_flat, group=self.group, overlap=self.overlap_exchange)
+        W.pipelined_all_reduce(p.rows, produce, p.slot_flat, group=self.group, overlap=self.overlap_exchange, n_owned=len(p.mine))
         if p.slot_graphs is None:
             self._sum_slots(p)
         else:

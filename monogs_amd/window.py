@@ -53,20 +53,32 @@ def all_gather_into_(out: torch.Tensor, inp: torch.Tensor, group=None):
     dist.all_gather_into_tensor(out, inp, group=group)
 
 
-def pipelined_all_reduce(n_slots: int, produce, buffers: Sequence[torch.Tensor], group=None, overlap: bool = True) -> None:
+def pipelined_all_reduce(n_slots: int, produce, buffers: Sequence[torch.Tensor], group=None, overlap: bool = True,
+                         n_owned: Optional[int] = None) -> None:
     """SUM-all-reduce ``buffers[j]`` for every slot j, where ``produce(j)`` queues the work that fills ``buffers[j]`` (one
     owned keyframe's render + backward).  ``overlap``: slot j's collective is issued right behind ``produce(j)``,
     asynchronously, so that it runs while ``produce(j + 1)`` executes (RCCL: on the communicator's stream, ordered behind
     the producer by an event); otherwise all collectives are issued after the last producer.  Same collectives, same data,
     same order either way -- the results are bit-identical, only the timing differs.  Returns when every collective has been
-    waited for (the caller's stream then sees the reduced buffers)."""
+    waited for (the caller's stream then sees the reduced buffers).
+
+    ``n_slots`` must be the SAME on every rank -- ``rows_per_rank(window, world)``, not the number of keyframes this rank
+    happens to own: with ``k % world`` sharding a window that is not a multiple of the world size (a SLAM window growing from
+    1 to 8 keyframes passes through every size) leaves some ranks one keyframe short, and ranks that disagree on the number or
+    the sizes of their collectives hang or reduce garbage.  ``n_owned`` (default: all) is how many of the slots this rank fills;
+    the others contribute zeros (the in-place all-reduce leaves the other ranks' sum in them, so they are cleared each time)."""
+    n_owned = n_slots if n_owned is None else int(n_owned)
+    assert 0 <= n_owned <= n_slots <= len(buffers)
     works = []
     for j in range(n_slots):
-        produce(j)
+        if j < n_owned:
+            produce(j)
+        else:
+            buffers[j].zero_()
         if overlap:
             works.append(all_reduce_(buffers[j], group=group, async_op=True))
     if not overlap:
-        works = [all_reduce_(b, group=group, async_op=True) for b in buffers]
+        works = [all_reduce_(b, group=group, async_op=True) for b in buffers[:n_slots]]
     for w in works:
         if w is not None:
             w.wait()

@@ -228,10 +228,12 @@ def test_c2_100k_mapping_loss_gradients(native_lib):
 @pytest.mark.parametrize("pose_only", [False, True])
 @pytest.mark.parametrize("P,intr,seed", [(5000, "fr3_office", 0), (100000, "fr3_office", 1), (60000, "replica", 4)])
 def test_blend_backward_paths_agree(native_lib, P, intr, seed, pose_only):
-    """The two blend backwards -- `blend_backward_t_kernel` (default: per-pixel factors through LDS, one row reduction per
-    four survivors) and `blend_backward_kernel` (its A/B partner behind mgs_debug_set_option("blend_bwd_transposed", 0): one
-    64-lane reduction per survivor) -- form the same sums in a different order: every gradient agrees to 1e-6 relative L2,
-    in the ten-sum and in the six-sum (pose-only: the map takes no gradient) variant."""
+    """The three blend backwards -- `blend_backward_q_kernel` (default since round 5: survivors' records through a compacted
+    per-wave LDS queue, per-pixel side under a narrowed EXEC, one row reduction per four survivors), `blend_backward_t_kernel`
+    (round 3: the same transposed accumulation fed by scalar loads; mgs_debug_set_option("blend_bwd_transposed", 1)) and
+    `blend_backward_kernel` (option 0: one 64-lane reduction per survivor) -- form the same sums; the first two in the same
+    order per batch, the third in another: every gradient agrees to 1e-6 relative L2, in the ten-sum and in the six-sum
+    (pose-only: the map takes no gradient) variant."""
     from monogs_amd.rasterizer import GaussianRasterizer
     sc = make_scene(P, intr, seed=seed)
     st = _hip_settings(sc)
@@ -252,18 +254,21 @@ def test_blend_backward_paths_agree(native_lib, P, intr, seed, pose_only):
             g.update({k: v.grad.clone() for k, v in leaves.items()}, means2D=m2.grad.clone())
         return g
     try:
-        native_lib.mgs_debug_set_option(b"blend_bwd_transposed", 1)
+        native_lib.mgs_debug_set_option(b"blend_bwd_transposed", 2)
         a = run()
-        native_lib.mgs_debug_set_option(b"blend_bwd_transposed", 0)
-        b = run()
-    finally:
         native_lib.mgs_debug_set_option(b"blend_bwd_transposed", 1)
-    assert set(a) == set(b) and len(a) == (2 if pose_only else 8)
-    for k in a:
-        x, y = a[k].double(), b[k].double()
-        assert y.norm() > 0, k
-        rel = ((x - y).norm() / y.norm()).item()
-        assert rel <= (1e-5 if k in ("theta", "rho") else 1e-6), (k, rel)      # (6 floats summed over the whole map)
+        b1 = run()
+        native_lib.mgs_debug_set_option(b"blend_bwd_transposed", 0)
+        b0 = run()
+    finally:
+        native_lib.mgs_debug_set_option(b"blend_bwd_transposed", 2)
+    for b in (b1, b0):
+        assert set(a) == set(b) and len(a) == (2 if pose_only else 8)
+        for k in a:
+            x, y = a[k].double(), b[k].double()
+            assert y.norm() > 0, k
+            rel = ((x - y).norm() / y.norm()).item()
+            assert rel <= (1e-5 if k in ("theta", "rho") else 1e-6), (k, rel)      # (6 floats summed over the whole map)
 
 
 def test_knn(native_lib):

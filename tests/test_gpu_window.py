@@ -270,13 +270,14 @@ def test_c4_window_two_ranks_match_one_rank_captured(native_lib, tmp_path):
     _check_windows_agree(r0, one, n_kf, iters)
 
 
-@pytest.mark.parametrize("use_graph", [False, True])
-def test_pipelined_exchange_window_matches_single_process(native_lib, tmp_path, use_graph):
+@pytest.mark.parametrize("use_graph,n_kf", [(False, 4), (True, 4), (False, 3), (True, 3)])
+def test_pipelined_exchange_window_matches_single_process(native_lib, tmp_path, use_graph, n_kf):
     """`exchange = "per_keyframe"`: with two keyframes per rank every owned keyframe's gradients are all-reduced on their own,
     issued behind its backward while the next keyframe renders (eager: one (render, loss, backward) per keyframe; captured: one
     graph per keyframe, the collectives between the replays), then added in keyframe order.  Against the single-process
     window the result differs by summation order only; the two replicas hold the same bits."""
-    out, iters, n_kf = str(tmp_path / "pk"), 10, 4
+    # (n_kf = 3: rank 1 owns ONE keyframe, rank 0 two -- both must issue two slot collectives of the same size)
+    out, iters = str(tmp_path / "pk"), 10
     args = (n_kf, "fr3_office", 20000, 8, iters)
     mp.spawn(_run_c4, args=(2, _free_port(), out, use_graph) + args + ("p", "per_keyframe"), nprocs=2, join=True)
     mp.spawn(_run_c4, args=(1, 0, out, use_graph) + args + ("p",), nprocs=1, join=True)

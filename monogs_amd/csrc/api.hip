@@ -415,6 +415,8 @@ int mgs_debug_set_option(const char* name, int64_t value) {
     if (name && !strcmp(name, "dup_slot_major")) { g_opt_dup_slot_major = (int)value; return 0; }
     if (name && !strcmp(name, "blend_bwd_transposed")) { g_opt_blend_bwd_transposed = (int)value; return 0; }
     if (name && !strcmp(name, "scan_small")) { g_opt_scan_small = (int)value; return 0; }
+    if (name && !strcmp(name, "blend_lds_pad_fwd")) { g_opt_blend_lds_pad_fwd = (int)value; return 0; }
+    if (name && !strcmp(name, "blend_lds_pad_bwd")) { g_opt_blend_lds_pad_bwd = (int)value; return 0; }
     if (name && !strcmp(name, "knn_grid_min")) { g_opt_knn_grid_min = value > 0x7FFFFFFF ? 0x7FFFFFFF : (int)value; return 0; }
     set_error("mgs_debug_set_option: unknown option");
     return 1;

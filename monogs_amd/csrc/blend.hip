@@ -25,11 +25,30 @@
 
 namespace mgs {
 
+extern int g_opt_blend_lds_pad_fwd, g_opt_blend_lds_pad_bwd;
+#ifdef BS_TRACE
+// Diagnostic build only (tools/build_variant.sh trace blend.hip -DBS_TRACE; tools/wave_timeline.py): every wave of the two blend
+// kernels leaves {start, end} (s_memrealtime, 100 MHz), its hardware id and the survivors it evaluated in a buffer of its own.
+static unsigned long long* g_trace_fwd = nullptr;
+static unsigned long long* g_trace_bwd = nullptr;
+#define BS_STAMP(v) asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory")
+#endif
+
 __device__ __forceinline__ uint32_t bcast(uint32_t v, int lane) {
     return (uint32_t)__builtin_amdgcn_readlane((int)v, lane);
 }
 
+// One 256-thread workgroup per 16x16 tile, wave w = quadrant w.  (Round 5 measured one 64-thread workgroup per (tile, quadrant),
+// launched as one contiguous band of quadrants per XCD, so that wave slots refill one by one instead of four at a time: C5
+// backward 0.335 / 0.343 against 0.345 / 0.333 ms, forward 0.190 / 0.192 against 0.194 / 0.189 -- nothing)
+constexpr int MGS_WG_WAVES = 4;
+#define MGS_TILE_WAVE(ntiles_, tile_, wave_, ws_)                                                   \
+    const int tile_ = (int)blockIdx.x, wave_ = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), ws_ = wave_; \
+    if (tile_ >= (ntiles_)) return;
 struct BlendArgs {
+#ifdef BS_TRACE
+    unsigned long long* trace;
+#endif
     const float4* __restrict__ rec;            // [P][4]
     const uint32_t* __restrict__ point_list;
     const uint2* __restrict__ ranges;
@@ -176,9 +195,10 @@ __global__ void __launch_bounds__(256) blend_forward_kernel(BlendArgs a, float* 
                                                             uint2* __restrict__ ranges_rw,
                                                             const uint32_t* __restrict__ sort_err,
                                                             uint32_t* __restrict__ status) {
-    const int tile = blockIdx.x;
+    MGS_TILE_WAVE(a.gx * ((a.H + TILE - 1) / TILE), tile, wave, ws)
     const int tx = tile % a.gx, ty = tile / a.gx;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63;
+    const bool first_of_tile = wave == 0 && lane == 0;
     const int qx0i = tx * TILE + (wave & 1) * SUB, qy0i = ty * TILE + (wave >> 1) * SUB;
     const int pxi = qx0i + (lane & 7), pyi = qy0i + (lane >> 3);
     const bool inside = pxi < a.W && pyi < a.H;
@@ -191,10 +211,10 @@ __global__ void __launch_bounds__(256) blend_forward_kernel(BlendArgs a, float* 
     uint2 range = a.ranges[tile];
     {
         const bool sort_bad = sort_err != nullptr && radix_failed(sort_err) != 0u;
-        if (sort_bad && tile == 0 && threadIdx.x == 0 && status) atomicOr(status, (uint32_t)MGS_STATUS_TILE_SORT_TIMEOUT);
+        if (sort_bad && tile == 0 && first_of_tile && status) atomicOr(status, (uint32_t)MGS_STATUS_TILE_SORT_TIMEOUT);
         if (sort_bad || range.x >= range.y) {
             range = make_uint2(0u, 0u);
-            if (threadIdx.x == 0) ranges_rw[tile] = range;
+            if (first_of_tile) ranges_rw[tile] = range;
         }
     }
 
@@ -206,6 +226,10 @@ __global__ void __launch_bounds__(256) blend_forward_kernel(BlendArgs a, float* 
     float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f;
     uint32_t last = 0;
     unsigned long long live = __builtin_amdgcn_ballot_w64(inside);
+#ifdef BS_TRACE
+    unsigned long long tr0;
+    BS_STAMP(tr0);
+#endif
 
     uint32_t gid_n = 0;
     float4 box_n = make_float4(0.f, 0.f, -1.f, -1.f), ell_n = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -260,11 +284,11 @@ __global__ void __launch_bounds__(256) blend_forward_kernel(BlendArgs a, float* 
         else walk_step(std::false_type{}, base, gid_l, mask);
     }
 #else
-    __shared__ __attribute__((aligned(16))) float4 s_queue[4][WAVE][3];
+    __shared__ __attribute__((aligned(16))) float4 s_queue[MGS_WG_WAVES][WAVE][3];
     float4 c1_n = make_float4(0.f, 0.f, 0.f, 0.f), c2_n = c1_n;
-    float4* const my_entry = &s_queue[wave][lane][0];
+    float4* const my_entry = &s_queue[ws][lane][0];
     // LDS byte address of this wave's queue, in a scalar register: an entry's address is then scalar arithmetic + one v_mov
-    const uint32_t q_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)&s_queue[threadIdx.x >> 6][0][0]);
+    const uint32_t q_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)&s_queue[ws][0][0]);
     auto prefetch = [&](uint32_t i) {               // next step's index + cull data, issued one step ahead
         gid_n = 0;
         box_n = make_float4(0.f, 0.f, -1.f, -1.f);
@@ -311,6 +335,17 @@ __global__ void __launch_bounds__(256) blend_forward_kernel(BlendArgs a, float* 
         else walk_step(std::false_type{}, base, gid_l, mask);
     }
 #endif
+#ifdef BS_TRACE
+    if (a.trace) {
+        unsigned long long tr1;
+        BS_STAMP(tr1);
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+        if (lane == 0) {
+            unsigned long long* o = a.trace + ((size_t)tile * 4 + wave) * 4;
+            o[0] = tr0; o[1] = tr1; o[2] = (unsigned long long)hw | ((unsigned long long)xcc << 32); o[3] = range.y - range.x;
+        }
+    }
+#endif
     if (inside) {
         const size_t pix = (size_t)pyi * a.W + pxi, HW = (size_t)a.H * a.W;
         final_T[pix] = T;
@@ -326,6 +361,9 @@ __global__ void __launch_bounds__(256) blend_forward_kernel(BlendArgs a, float* 
 static BlendArgs make_args(const mgs_camera& cam, const GeometryState& g, const BinningState& b,
                            const ImageState& img) {
     BlendArgs a;
+#ifdef BS_TRACE
+    a.trace = nullptr;
+#endif
     a.rec = reinterpret_cast<const float4*>(g.rec);
     a.point_list = b.vals_sorted;
     a.ranges = img.ranges;
@@ -339,10 +377,14 @@ static BlendArgs make_args(const mgs_camera& cam, const GeometryState& g, const 
 int launch_blend_forward(const mgs_camera& cam, const GeometryState& g, const BinningState& b,
                          const ImageState& img, float* out_color, float* out_depth, float* out_opacity,
                          int32_t* n_touched, const uint32_t* sort_err, uint32_t* status, hipStream_t s) {
-    const BlendArgs a = make_args(cam, g, b, img);
+    BlendArgs a = make_args(cam, g, b, img);
+#ifdef BS_TRACE
+    a.trace = g_trace_fwd;
+#endif
     const int ntiles = a.gx * tiles_y(a.H);
     if (ntiles == 0) return 0;
-    hipLaunchKernelGGL(blend_forward_kernel, dim3(ntiles), dim3(256), 0, s, a, out_color, out_depth, out_opacity,
+    const dim3 grid(ntiles), block(256);
+    hipLaunchKernelGGL(blend_forward_kernel, grid, block, (size_t)g_opt_blend_lds_pad_fwd, s, a, out_color, out_depth, out_opacity,
                        img.final_T, img.n_contrib, n_touched, img.ranges, sort_err, status);
     MGS_HIP(hipGetLastError());
     return 0;
@@ -563,6 +605,9 @@ __global__ void __launch_bounds__(256) blend_backward_kernel(BlendArgs a, int nt
 // transposition is exact (same products, different summation order).
 // =================================================================================================
 constexpr int BT_SLOTS = 4;                      // survivors per batch = rows of 16 lanes
+constexpr int BS_STRIDE = 272;                   // slot stride of blend_backward_s_kernel's slab and metadata (bytes)
+constexpr int BS_W_OFF = 1280;                   // w factors behind the h factors: a multiple of 256 (ds_write2st64 offset) >= 4 x 272
+constexpr int BS_META_OFF = BS_W_OFF + BT_SLOTS * BS_STRIDE;      // 2368
 // which gradient slot the lane (t = lane & 15) of a row holds after reduce_rows (see there); -1: none
 __device__ __forceinline__ int bt_slot10(int t) {
     const int bank = t >> 2, m = t & 3;
@@ -669,9 +714,11 @@ __device__ __forceinline__ void bt_flush(const BtLane L, int n) {
     int lane = L.lane;
     asm volatile("" : "+v"(lane));
     const int q = lane & 15, row = lane >> 4;
-    const float4 h4 = *reinterpret_cast<const float4*>(L.fac + 4 * lane);                   // [row][4 q .. 4 q + 3]
-    const float4 w4 = *reinterpret_cast<const float4*>(L.fac + BT_SLOTS * WAVE + 4 * lane);
-    const BtMetaRec me = L.meta[WIDE_META ? row * 16 : row];
+    // [row][4 q .. 4 q + 3]; WIDE_META (blend_backward_s_kernel): rows BS_STRIDE bytes apart in all three arrays
+    const float* const hp = WIDE_META ? L.fac + row * (BS_STRIDE / 4) + 4 * q : L.fac + 4 * lane;
+    const float4 h4 = *reinterpret_cast<const float4*>(hp);
+    const float4 w4 = *reinterpret_cast<const float4*>(hp + (WIDE_META ? BS_W_OFF / 4 : BT_SLOTS * WAVE));
+    const BtMetaRec me = L.meta[WIDE_META ? row * (BS_STRIDE / 16) : row];
     // [channel][q][4]: the sixteen lanes of a row read 256 contiguous bytes per channel (conflict-free; laid out [q][channel]
     // the 64-byte lane stride put four lanes on every bank: 48 M conflict cycles per launch at C5, r03 PMC)
     const float* const fp = L.pix + q * 4;
@@ -871,14 +918,17 @@ __global__ void __launch_bounds__(256) blend_backward_s_kernel(BlendArgs a, int 
                                                                const float* __restrict__ dL_dcolor,
                                                                const float* __restrict__ dL_ddepth,
                                                                float* __restrict__ grad_acc) {
-    // per wave: the factor slab [h | w][slot][pixel] (2 KB), then the slots' metadata {cx, cy, index << 6}, 256 bytes apart like
-    // the slots themselves: ONE scalar (slab base + open slot x 256) addresses both
-    struct WaveLds { float fac[2][BT_SLOTS][WAVE]; BtMetaRec meta[BT_SLOTS][16]; };
-    __shared__ __attribute__((aligned(16))) WaveLds s_w[4];
-    __shared__ __attribute__((aligned(16))) float s_pix[4][POSE_ONLY ? 1 : 4][16][4];    // [wave][(rgb,) depth][q][4 pixels]
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-    const int tile = (int)blockIdx.x;
-    if (tile >= ntiles) return;
+    // per wave: the factor slab [h | w][slot][pixel] and the slots' metadata {cx, cy, index << 6}, every array with the SAME slot
+    // stride so that ONE scalar (slab base + open slot x stride) addresses all three -- 272 bytes, not 256: the flush's four
+    // rows read their metadata at once, and 256 bytes apart those words share their LDS banks (7.9 M conflict cycles per launch
+    // at C5, r05 PMC)
+    struct WaveLds { float h[BT_SLOTS][BS_STRIDE / 4]; float pad[(BS_W_OFF - BT_SLOTS * BS_STRIDE) / 4]; float w[BT_SLOTS][BS_STRIDE / 4];
+                     BtMetaRec meta[BT_SLOTS][BS_STRIDE / 16]; };
+    static_assert(sizeof(WaveLds) == BS_META_OFF + BT_SLOTS * BS_STRIDE, "layout");
+    __shared__ __attribute__((aligned(16))) WaveLds s_w[MGS_WG_WAVES];
+    __shared__ __attribute__((aligned(16))) float s_pix[MGS_WG_WAVES][POSE_ONLY ? 1 : 4][16][4];    // [wave][(rgb,) depth][q][4 pixels]
+    MGS_TILE_WAVE(ntiles, tile, wave, ws)
+    const int lane = threadIdx.x & 63;
     const int tx = tile % a.gx, ty = tile / a.gx;
     const uint2 range = a.ranges[tile];
     if (range.y <= range.x) return;
@@ -901,6 +951,11 @@ __global__ void __launch_bounds__(256) blend_backward_s_kernel(BlendArgs a, int 
     const uint32_t maxc = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max_u32(last));
     if (maxc == 0) return;
     const uint32_t end = range.x + maxc;
+#ifdef BS_TRACE
+    unsigned long long tr0;
+    uint32_t tr_n = 0;
+    BS_STAMP(tr0);
+#endif
 
     const int q = lane & 15;
     const int fxi = qx0i + 4 * (q & 1), fyi = qy0i + (q >> 1);
@@ -910,21 +965,21 @@ __global__ void __launch_bounds__(256) blend_backward_s_kernel(BlendArgs a, int 
             const bool in_i = (fxi + i) < a.W && fyi < a.H;
             const size_t px_i = (size_t)fyi * a.W + fxi + i;
             if (!POSE_ONLY) {
-                s_pix[wave][0][q][i] = in_i ? dL_dcolor[px_i] : 0.f;
-                s_pix[wave][1][q][i] = in_i ? dL_dcolor[HW + px_i] : 0.f;
-                s_pix[wave][2][q][i] = in_i ? dL_dcolor[2 * HW + px_i] : 0.f;
+                s_pix[ws][0][q][i] = in_i ? dL_dcolor[px_i] : 0.f;
+                s_pix[ws][1][q][i] = in_i ? dL_dcolor[HW + px_i] : 0.f;
+                s_pix[ws][2][q][i] = in_i ? dL_dcolor[2 * HW + px_i] : 0.f;
             }
-            s_pix[wave][POSE_ONLY ? 0 : 3][q][i] = in_i ? dL_ddepth[px_i] : 0.f;
+            s_pix[ws][POSE_ONLY ? 0 : 3][q][i] = in_i ? dL_ddepth[px_i] : 0.f;
         }
     }
     const int slot = POSE_ONLY ? bt_slot6(q) : bt_slot10(q);
     const uint32_t slot_bytes = slot < 0 ? 0u : (uint32_t)slot * 4u;
     const unsigned long long m_out = __builtin_amdgcn_ballot_w64(slot >= 0);
     const unsigned long long m_q0 = __builtin_amdgcn_ballot_w64((q & 3) == 0), m_q1 = __builtin_amdgcn_ballot_w64((q & 3) == 1);
-    const BtLane bl{&s_w[wave].fac[0][0][0], &s_pix[wave][0][0][0], &s_w[wave].meta[0][0], lane, 0.f, 0.f, slot_bytes, m_out, m_q0, m_q1, grad_acc, qx0i, qy0i};
-    const uint32_t wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)&s_w[threadIdx.x >> 6]);   // LDS address (SGPR)
+    const BtLane bl{&s_w[ws].h[0][0], &s_pix[ws][0][0][0], &s_w[ws].meta[0][0], lane, 0.f, 0.f, slot_bytes, m_out, m_q0, m_q1, grad_acc, qx0i, qy0i};
+    const uint32_t wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)&s_w[ws]);   // LDS address (SGPR)
     const const_float_p recs = MGS_CONST(reinterpret_cast<const float*>(a.rec));
-    uint32_t koff = 0;              // open batch: survivors x 256 = byte offset of the open slot in the slab and in the metadata (SGPR)
+    uint32_t koff = 0;              // open batch: survivors x 272 = byte offset of the open slot in the slab and in the metadata (SGPR)
     float zero = 0.f;
     asm volatile("" : "+v"(zero));  // (a VGPR holding 0: data operand of the slot-clearing LDS store)
 
@@ -982,7 +1037,7 @@ __global__ void __launch_bounds__(256) blend_backward_s_kernel(BlendArgs a, int 
                     "v_exp_f32_e32 %[G], %[t2]\n\t"
                     "s_add_u32 %[tmp], %[wbase], %[koff]\n\t"               // the open slot
                     "v_lshl_add_u32 %[sa], %[lane], 2, %[tmp]\n\t"           // this lane's word of it
-                    "ds_write2st64_b32 %[sa], %[zero], %[zero] offset1:4\n\t"   // the slot's h and w of every pixel <- 0 (full EXEC)
+                    "ds_write2st64_b32 %[sa], %[zero], %[zero] offset1:5\n\t"   // the slot's h and w of every pixel <- 0 (full EXEC)
                     "v_cmpx_ge_i32_e32 vcc, %[j], %[thr]\n\t"              // EXEC: pixels whose last contributor is not in front of j
                     "v_cmpx_nlt_f32_e32 vcc, 0, %[t2]\n\t"                 //       and power <= 0
                     "v_mul_f32_e32 %[al], %[op], %[G]\n\t"
@@ -1001,12 +1056,12 @@ __global__ void __launch_bounds__(256) blend_backward_s_kernel(BlendArgs a, int 
                     "v_mul_f32_e32 %[dx], %[G], %[dx]\n\t"                 // h = G dL/dalpha
                     "v_mul_f32_e32 %[dy], %[al], %[T]\n\t"                 // w = alpha T
                     "v_fmac_f32_e32 %[Bk], %[al], %[qq]\n\t"               // Bk <- Bk + alpha diff
-                    "ds_write2st64_b32 %[sa], %[dx], %[dy] offset1:4\n\t"  // (active pixels only)
+                    "ds_write2st64_b32 %[sa], %[dx], %[dy] offset1:5\n\t"  // (active pixels only)
                     "s_cmp_lg_u64 exec, 0\n\t"
-                    "s_cselect_b32 %[adv], 256, 0\n\t"                     // the slot is taken only if some pixel was active
+                    "s_cselect_b32 %[adv], 272, 0\n\t"                     // the slot is taken only if some pixel was active
                     "s_lshl_b64 exec, 1, %[j]\n\t"                         // lane j: the slot's metadata {centre, index << 6}
                     "v_mov_b32_e32 %[sa], %[tmp]\n\t"
-                    "ds_write_b96 %[sa], %[meta] offset:2048\n\t"
+                    "ds_write_b96 %[sa], %[meta] offset:2368\n\t"
                     "s_mov_b64 exec, -1\n\t"
                     : [dx] "=&v"(dx), [dy] "=&v"(dy), [t1] "=&v"(t1), [t2] "=&v"(t2), [G] "=&v"(G), [al] "=&v"(al), [inv] "=&v"(inv),
                       [qq] "=&v"(qq), [sa] "=&v"(sa), [T] "+v"(T), [Bk] "+v"(Bk), [adv] "=&s"(adv), [tmp] "=&s"(tmp)
@@ -1016,11 +1071,14 @@ __global__ void __launch_bounds__(256) blend_backward_s_kernel(BlendArgs a, int 
                       [koff] "s"(koff), [wbase] "s"(wbase), [meta] "v"(meta), [amin] "s"(1.0f / 255.0f)
                     : "vcc", "scc", "memory");
                 koff += adv;
-            if (koff == BT_SLOTS * 256) {
+            if (koff == BT_SLOTS * BS_STRIDE) {
                 bt_flush<POSE_ONLY, true>(bl, BT_SLOTS);
                 koff = 0;
             }
         };
+#ifdef BS_TRACE
+        tr_n += (uint32_t)__popcll(mask);
+#endif
         if (mask) {
             int jA, jB = 0;
             v2f a0, b0;
@@ -1042,6 +1100,17 @@ __global__ void __launch_bounds__(256) blend_backward_s_kernel(BlendArgs a, int 
 #undef BS_POP
     }
     if (koff) bt_flush<POSE_ONLY, true>(bl, (int)(koff >> 8));
+#ifdef BS_TRACE
+    if (a.trace) {
+        unsigned long long tr1;
+        BS_STAMP(tr1);
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+        if (lane == 0) {
+            unsigned long long* o = a.trace + ((size_t)tile * 4 + wave) * 4;
+            o[0] = tr0; o[1] = tr1; o[2] = (unsigned long long)hw | ((unsigned long long)xcc << 32); o[3] = tr_n;
+        }
+    }
+#endif
 }
 
 // ---- diagnostic: what the backward walk does, counted (not on the hot path; mgs_debug_blend_stats) --------------
@@ -1219,19 +1288,24 @@ int launch_blend_backward_stats(const mgs_camera& cam, const GeometryState& g, c
 
 // (The wave-per-tile and half-tile-per-wave variants of round 1 lost at every size and are gone; DESIGN.md section 4
 //  keeps their measurements.)
+int g_opt_blend_lds_pad_fwd = 0, g_opt_blend_lds_pad_bwd = 0;      // measurement knobs: dynamic LDS bytes the kernels never touch (fewer workgroups per CU)
 int g_opt_blend_bwd_transposed = 2;     // mgs_debug_set_option("blend_bwd_transposed", 0 | 1 | 2): 2 = scalar side trimmed + EXEC (round 5), 1 = scalar-fetch transposed (round 3), 0 = the per-survivor wave reduction
 int launch_blend_backward(const mgs_camera& cam, const GeometryState& g, const BinningState& b,
                           const ImageState& img, const float* dL_dcolor, const float* dL_ddepth, float* grad_acc,
                           bool pose_only, hipStream_t s) {
-    const BlendArgs a = make_args(cam, g, b, img);
+    BlendArgs a = make_args(cam, g, b, img);
+#ifdef BS_TRACE
+    a.trace = g_trace_bwd;
+#endif
     const int ntiles = a.gx * tiles_y(a.H);
     if (ntiles == 0) return 0;
     if (g_opt_blend_bwd_transposed == 2) {
+        const dim3 grid(ntiles), block(256);
         if (pose_only)
-            hipLaunchKernelGGL((blend_backward_s_kernel<true>), dim3(ntiles), dim3(256), 0, s, a, ntiles, img.final_T,
+            hipLaunchKernelGGL((blend_backward_s_kernel<true>), grid, block, (size_t)g_opt_blend_lds_pad_bwd, s, a, ntiles, img.final_T,
                                img.n_contrib, dL_dcolor, dL_ddepth, grad_acc);
         else
-            hipLaunchKernelGGL((blend_backward_s_kernel<false>), dim3(ntiles), dim3(256), 0, s, a, ntiles, img.final_T,
+            hipLaunchKernelGGL((blend_backward_s_kernel<false>), grid, block, (size_t)g_opt_blend_lds_pad_bwd, s, a, ntiles, img.final_T,
                                img.n_contrib, dL_dcolor, dL_ddepth, grad_acc);
     } else if (g_opt_blend_bwd_transposed != 0) {
         if (pose_only)
@@ -1268,3 +1342,11 @@ int launch_valu_ceiling(float* out, int iters, hipStream_t s) {
 }
 
 }  // namespace mgs
+
+#ifdef BS_TRACE
+extern "C" int mgs_trace_set_blend_buffers(void* fwd, void* bwd) {      // diagnostic builds only: device buffers of 4 x tiles x 4 uint64, or NULL
+    mgs::g_trace_fwd = (unsigned long long*)fwd;
+    mgs::g_trace_bwd = (unsigned long long*)bwd;
+    return 0;
+}
+#endif

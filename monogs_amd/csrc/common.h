@@ -241,7 +241,7 @@ int launch_depth_sort(const GeometryState& g, int P, bool payload, hipStream_t s
 int launch_sort(const GeometryState& g, const BinningState& b, uint64_t R, int bits, hipStream_t s,
                 const uint32_t* n_dev = nullptr, bool exclusive = false, uint2* ranges = nullptr);
 int set_radix_spin_limit(uint32_t limit);
-extern int g_opt_radix_ballot_rank, g_opt_radix_scanned, g_opt_radix_xcd_band, g_opt_radix_tile_items, g_opt_knn_grid_min, g_opt_scan_small, g_opt_dup_slot_major, g_opt_blend_bwd_transposed;      // test knobs (mgs_debug_set_option)
+extern int g_opt_radix_ballot_rank, g_opt_radix_scanned, g_opt_radix_xcd_band, g_opt_radix_tile_items, g_opt_knn_grid_min, g_opt_scan_small, g_opt_dup_slot_major, g_opt_blend_bwd_transposed, g_opt_blend_lds_pad_fwd, g_opt_blend_lds_pad_bwd;      // test knobs (mgs_debug_set_option)
 // `sort_err`: the tile sort's error words (NULL: nothing was sorted); a raised word empties every tile and sets
 // MGS_STATUS_TILE_SORT_TIMEOUT in *status (what ranges_kernel did until round 4)
 int launch_blend_forward(const mgs_camera& cam, const GeometryState& g, const BinningState& b,

@@ -160,9 +160,12 @@ int mgs_debug_set_radix_spin_limit(uint32_t limit);
 /* Test knobs that force an algorithm path whatever the problem size (process-wide; -1 restores the default):
  * "radix_scanned" (0 = one kernel per pass with a gather of the earlier tiles' counts, 1 = counted tiles: two kernels per
  * pass, no waiting between workgroups -- honoured from 64 k pairs), "radix_ballot_rank" (1 = rank with wave ballots instead of
- * returning LDS atomics: the reference the sort tests compare with), "scan_small" (0 = the two-launch scan at every size),
+ * returning LDS atomics: the reference the sort tests compare with), "scan_small" (0 = the two-launch scan at every size), "depth_small" (1 = maps <= 24 576 Gaussians run
+ * depth sort + rectangle gather + scan as ONE single-workgroup launch: measured slower, off by default), "blend_lds_pad_fwd" / "blend_lds_pad_bwd" (dynamic
+ * LDS bytes the blend kernels never touch: fewer workgroups per compute unit, a measurement knob),
  * "dup_slot_major" (0 / 1 = the duplicate kernel's emission balanced by Gaussians / by output slots at every size),
- * "knn_grid_min" (Morton-box kNN from this many points), "blend_bwd_transposed" (0 = the per-survivor blend backward),
+ * "knn_grid_min" (Morton-box kNN from this many points), "blend_bwd_transposed" (2 = default, 1 = round 3's transposed blend
+ * backward fed by per-survivor scalar loads, 0 = the per-survivor wave reduction),
  * "radix_xcd_band" (0 = counted tiles in block-id order instead of one contiguous band of tiles per XCD), "radix_tile_items"
  * (8 | 12 | 16 pairs per thread on the counted-tiles path, 0 = by size; set it before any scratch is sized),
  * "debug_sort_exclusive" (1 = mgs_debug_sort_pairs sorts as under MGS_FLAG_EXCLUSIVE_DEVICE).  Nothing on the launch path

@@ -188,9 +188,14 @@ int mgs_forward_preprocess(const mgs_camera* cam, int32_t P, const float* means3
                                            prepare_backward ? backward_grad_acc(prepare_backward) : nullptr, s)) return rc;
     tm.mark();
     const bool exclusive = (cam->flags & MGS_FLAG_EXCLUSIVE_DEVICE) != 0;
-    if (int rc = launch_depth_sort(g, P, depth_sort_payload(P, cam->image_width, cam->image_height), s, exclusive)) return rc;
-    tm.mark();
-    if (int rc = launch_scan(g, P, s, exclusive)) return rc;
+    if (depth_chain_is_small(P)) {          // one single-workgroup launch: sort, rectangle gather and scan (timed as the depth sort)
+        if (int rc = launch_depth_chain_small(g, P, s)) return rc;
+        tm.mark();
+    } else {
+        if (int rc = launch_depth_sort(g, P, depth_sort_payload(P, cam->image_width, cam->image_height), s, exclusive)) return rc;
+        tm.mark();
+        if (int rc = launch_scan(g, P, s, exclusive)) return rc;
+    }
     tm.mark();
     if (num_rendered) {
         uint32_t total = 0, sort_errors[RADIX_ERROR_WORDS] = {0, 0, 0, 0};
@@ -415,6 +420,7 @@ int mgs_debug_set_option(const char* name, int64_t value) {
     if (name && !strcmp(name, "dup_slot_major")) { g_opt_dup_slot_major = (int)value; return 0; }
     if (name && !strcmp(name, "blend_bwd_transposed")) { g_opt_blend_bwd_transposed = (int)value; return 0; }
     if (name && !strcmp(name, "scan_small")) { g_opt_scan_small = (int)value; return 0; }
+    if (name && !strcmp(name, "depth_small")) { g_opt_depth_small = (int)value; return 0; }
     if (name && !strcmp(name, "blend_lds_pad_fwd")) { g_opt_blend_lds_pad_fwd = (int)value; return 0; }
     if (name && !strcmp(name, "blend_lds_pad_bwd")) { g_opt_blend_lds_pad_bwd = (int)value; return 0; }
     if (name && !strcmp(name, "knn_grid_min")) { g_opt_knn_grid_min = value > 0x7FFFFFFF ? 0x7FFFFFFF : (int)value; return 0; }

@@ -180,6 +180,176 @@ int launch_scan(const GeometryState& g, int P, hipStream_t s, bool exclusive) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Small maps (P <= DS_SMALL_MAX: what MonoGS's pruning leaves, 8 k - 25 k Gaussians): the WHOLE depth chain -- digit
+// histograms, four stable radix passes, the gather of the tile rectangles into depth order and the prefix sum of tiles
+// touched -- in ONE launch of ONE 1024-thread workgroup, everything resident in the compute unit's 160 KB of LDS.
+//
+// Inside a replayed tracking iteration that chain was six launches (rs_hist 4.8 us, four one-sweep passes 6.7 - 9.8 us each,
+// scan_small 4.9 us: 40.7 us of a 210 us iteration, profiles/r04_tracking_replay_kernel_sequence.txt), every one of them at
+// the floor of its own dependent round-trip chain through L2 (publish digit counts, gather the earlier tiles', scatter), for
+// <= 25 k keys that fit one CU.  Here nothing waits for another workgroup and nothing leaves the CU between the passes:
+//   * LDS: keys u32[24576] (96 KB) + indices u16[24576] (48 KB) + per-wave digit counters, two 16-bit counts to a word
+//     (16 waves x 128 words = 8 KB; a wave holds <= 1536 keys);
+//   * wave w owns the contiguous chunk [w * chunk, (w + 1) * chunk) of the array, row i of it is 64 consecutive elements:
+//     a pass reads its rows into registers (key, index), ranks every element among its wave's elements of the same digit with
+//     ONE returning LDS atomic (the radix sort's ranking: lanes of one DS instruction that hit one address are applied in
+//     ascending lane order, a wave's DS instructions in program order -- stable), the 256 digit columns of the 16 x 256 table
+//     are scanned by 256 threads, and the elements go back into the SAME arrays at their destinations (every element was
+//     read before the barrier in front of the first write);
+//   * after the last pass: perm[] (coalesced), the rectangles gathered through the sorted indices (a culled key -- all ones
+//     -- gets the empty rectangle without the fetch), w x h scanned row by row with the DPP wave scan, the waves joined
+//     through LDS, the grand total where scan_blocks_kernel leaves it.
+// Same keys, same stable LSD order: perm, rect_sorted and point_offsets are bit-identical to the multi-launch path
+// (tests/test_gpu_sort.py::test_small_depth_chain_matches_the_multi_launch_path; option "depth_small" = 0 disables it).
+// ------------------------------------------------------------------------------------------------
+constexpr int DS_THREADS = 1024, DS_WAVES = DS_THREADS / WAVE, DS_ROWS = 24;
+constexpr int DS_SMALL_MAX = DS_THREADS * DS_ROWS;          // 24 576
+__global__ void __launch_bounds__(DS_THREADS) depth_chain_small_kernel(const uint32_t* __restrict__ depth_key,
+                                                                       const uint2* __restrict__ rect,
+                                                                       uint32_t* __restrict__ perm, uint2* __restrict__ rect_sorted,
+                                                                       uint32_t* __restrict__ offsets,
+                                                                       uint32_t* __restrict__ grand_total, int n
+#ifdef DS_TRACE
+                                                                       , unsigned long long* trace
+#define DS_STAMP(i) do { __syncthreads(); if (threadIdx.x == 0) { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); trace[i] = t_; } } while (0)
+#else
+#define DS_STAMP(i) do { } while (0)
+#endif
+                                                                       ) {
+    __shared__ uint32_t s_key[DS_SMALL_MAX];
+    __shared__ uint16_t s_idx[DS_SMALL_MAX];
+    __shared__ uint32_t s_tab[DS_WAVES][128];                 // [wave][digit >> 1]: count of digit d in bits 16 (d & 1) .. +15
+    __shared__ uint32_t s_part[DS_WAVES];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int rows = (n + DS_THREADS - 1) / DS_THREADS;       // rows of 64 per wave (<= DS_ROWS)
+    const int chunk = rows * WAVE;
+    const int e0 = wv * chunk + lane;
+    // ---- load: key + index, in index order (the order stability refers to)
+#pragma unroll
+    for (int i = 0; i < DS_ROWS; ++i) {
+        const int e = e0 + i * WAVE;
+        if (i < rows && e < n) {
+            s_key[e] = depth_key[e];
+            s_idx[e] = (uint16_t)e;
+        }
+    }
+    uint16_t* const tab16 = reinterpret_cast<uint16_t*>(&s_tab[0][0]);     // [wave][digit] as 16-bit entries
+    DS_STAMP(0);
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 8 * pass;
+        for (int t = threadIdx.x; t < DS_WAVES * 128; t += DS_THREADS) (&s_tab[0][0])[t] = 0u;
+        __syncthreads();                                       // (also: the previous pass's / the load's LDS writes are visible)
+        uint32_t k[DS_ROWS], vr[DS_ROWS];                      // key; index << 16 | rank within (wave, digit)
+#pragma unroll
+        for (int i = 0; i < DS_ROWS; ++i) {
+            const int e = e0 + i * WAVE;
+            k[i] = 0u; vr[i] = 0u;
+            if (i < rows && e < n) {
+                k[i] = s_key[e];
+                const uint32_t d = (k[i] >> shift) & 255u, sh = 16u * (d & 1u);
+                const uint32_t old = atomicAdd(&s_tab[wv][d >> 1], 1u << sh);
+                vr[i] = ((uint32_t)s_idx[e] << 16) | ((old >> sh) & 0xFFFFu);
+            }
+        }
+        __syncthreads();
+        DS_STAMP(1 + 4 * pass);
+        // column scan: thread d < 256 turns the 16 per-wave counts of digit d into exclusive prefixes over the waves
+        uint32_t tot = 0;
+        if (threadIdx.x < 256) {
+#pragma unroll
+            for (int w = 0; w < DS_WAVES; ++w) {
+                const uint32_t c = tab16[w * 256 + threadIdx.x];
+                tab16[w * 256 + threadIdx.x] = (uint16_t)tot;
+                tot += c;
+            }
+        }
+        // exclusive scan of the 256 digit totals (threads of the first four waves), added to every wave's entry
+        if (threadIdx.x < 256) {
+            const uint32_t incl = wave_incl_scan_dpp(tot);
+            if (lane == 63) s_part[wv] = incl;
+            tot = incl - tot;                                  // exclusive within the wave
+        }
+        __syncthreads();
+        if (threadIdx.x < 256) {
+            uint32_t base = tot;
+            for (int w = 0; w < wv; ++w) base += s_part[w];
+#pragma unroll
+            for (int w = 0; w < DS_WAVES; ++w) tab16[w * 256 + threadIdx.x] = (uint16_t)(tab16[w * 256 + threadIdx.x] + base);
+        }
+        __syncthreads();
+        DS_STAMP(2 + 4 * pass);
+#pragma unroll
+        for (int i = 0; i < DS_ROWS; ++i) {
+            const int e = e0 + i * WAVE;
+            if (i < rows && e < n) {
+                const uint32_t d = (k[i] >> shift) & 255u;
+                const uint32_t dst = (uint32_t)tab16[wv * 256 + d] + (vr[i] & 0xFFFFu);
+                s_key[dst] = k[i];
+                s_idx[dst] = (uint16_t)(vr[i] >> 16);
+            }
+        }
+        __syncthreads();                                       // (every wave is done with the table before the next pass clears it)
+        DS_STAMP(3 + 4 * pass);
+    }
+    // ---- outputs, in depth order: perm, rect_sorted, inclusive sums of tiles touched
+    uint2 rc[DS_ROWS];
+#pragma unroll
+    for (int i = 0; i < DS_ROWS; ++i) {
+        const int e = e0 + i * WAVE;
+        rc[i] = make_uint2(0u, 0u);
+        if (i < rows && e < n) {
+            const uint32_t g = s_idx[e];
+            perm[e] = g;
+            if (s_key[e] != 0xFFFFFFFFu) rc[i] = rect[g];
+        }
+    }
+    DS_STAMP(17);
+    uint32_t incl[DS_ROWS], run = 0;
+#pragma unroll
+    for (int i = 0; i < DS_ROWS; ++i) {
+        const uint32_t tt = (rc[i].y & 0xFFFFu) * (rc[i].y >> 16);
+        const uint32_t sc = wave_incl_scan_dpp(tt);
+        incl[i] = run + sc;
+        run += (uint32_t)__builtin_amdgcn_readlane((int)sc, 63);
+    }
+    if (lane == 0) s_part[wv] = run;
+    __syncthreads();
+    uint32_t wbase = 0, total = 0;
+    for (int w = 0; w < DS_WAVES; ++w) {
+        const uint32_t p = s_part[w];
+        wbase += w < wv ? p : 0u;
+        total += p;
+    }
+#pragma unroll
+    for (int i = 0; i < DS_ROWS; ++i) {
+        const int e = e0 + i * WAVE;
+        if (i < rows && e < n) {
+            rect_sorted[e] = rc[i];
+            offsets[e] = incl[i] + wbase;
+        }
+    }
+    if (threadIdx.x == 0) *grand_total = total;
+    DS_STAMP(18);
+}
+// MEASURED, NOT THE DEFAULT (tools/ubench/depth_small_bench, 20 000 keys): 63 us against 40.7 us for the six launches --
+// count + rank 4.5 - 5.7 us per pass of evenly spread digits and 14.3 us for the exponent byte (64 lanes on three counters),
+// scatter 2.6 us, the rectangle gather 9.1 us (ONE compute unit's texture path takes one cache line per cycle), the stores 5 us:
+// a single CU's LDS and memory pipes are what 16 - 40 CUs share in the multi-launch path.  Replayed room run: tracking 4 525
+// against 5 467 it/s.  Kept behind mgs_debug_set_option("depth_small", 1) with its test; DESIGN.md section 4.
+int g_opt_depth_small = 0;          // mgs_debug_set_option("depth_small", 0 | 1): 1 = the single-workgroup chain for maps <= 24 576
+bool depth_chain_is_small(int P) { return g_opt_depth_small > 0 && P > 0 && P <= DS_SMALL_MAX; }
+int launch_depth_chain_small(const GeometryState& g, int P, hipStream_t s) {
+    hipLaunchKernelGGL(depth_chain_small_kernel, dim3(1), dim3(DS_THREADS), 0, s, g.depth_key, g.rect, g.perm, g.rect_sorted,
+                       g.point_offsets, g.scan_blocks + scan_nblocks(P), P
+#ifdef DS_TRACE
+                       , (unsigned long long*)nullptr
+#endif
+                       );
+    MGS_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // duplicate: thread i takes the i-th Gaussian in depth order and walks its tile rectangle
 // (y outer, x inner), emitting (tile id, Gaussian index)
 // ------------------------------------------------------------------------------------------------
@@ -417,7 +587,7 @@ int launch_duplicate(const mgs_camera& cam, int P, const GeometryState& g, const
     hipLaunchKernelGGL(duplicate_kernel, dim3(n_threads / 256), dim3(256), 0, s, P, g.rect_sorted, g.perm, g.point_offsets,
                        g.scan_blocks, b.keys_a, b.vals_a, tiles_x(cam.image_width), tiles_y(cam.image_height),
                        (uint32_t)(r_cap > 0xFFFFFFFFull ? 0xFFFFFFFFull : r_cap), n_touched, img.ranges, ntiles, zero_ptr,
-                       zero_words, count, overflow, depth_err, (P > 0 && scan_is_small(P)) ? 1 : 0,
+                       zero_words, count, overflow, depth_err, (P > 0 && (scan_is_small(P) || depth_chain_is_small(P))) ? 1 : 0,
                        count_digits ? g.tile_hist : nullptr, (sort_bits + 7) / 8, n_threads, slot_major ? 1 : 0);
     MGS_HIP(hipGetLastError());
     return 0;

@@ -307,16 +307,24 @@ __global__ void __launch_bounds__(256) blend_forward_kernel(BlendArgs a, float* 
         while (mask) {
             const int j = __builtin_ctzll(mask);
             mask &= ~(1ull << j);
-            float4 e0, e1, e2;                      // uniform address: three broadcast reads
+            // uniform address: three broadcast reads, each waited for where its values are first needed (LDS reads of a wave
+            // return in order): the centre arrives first and dx, dy start while the conic and the colour are still on their way
+            typedef float qv2 __attribute__((ext_vector_type(2)));
+            typedef float qv4 __attribute__((ext_vector_type(4)));
+            qv2 e0;
+            qv4 e1, e2;
             {
                 const uint32_t ad = q_base + (uint32_t)j * 48u;
-                asm volatile("ds_read_b64 %0, %3\n\tds_read_b128 %1, %3 offset:16\n\tds_read_b128 %2, %3 offset:32\n\ts_waitcnt lgkmcnt(0)"
-                             : "=&v"(*reinterpret_cast<float2*>(&e0)), "=&v"(e1), "=&v"(e2) : "v"(ad) : "memory");
+                asm volatile("ds_read_b64 %0, %3\n\tds_read_b128 %1, %3 offset:16\n\tds_read_b128 %2, %3 offset:32"
+                             : "=&v"(e0), "=&v"(e1), "=&v"(e2) : "v"(ad) : "memory");
             }
-            const Rec g{e0.x, e0.y, e1.x, e1.y, e1.z, e1.w, e2.x, e2.y, e2.z, e2.w};
-            const float dx = g.px - pxf, dy = g.py - pyf;
-            const float power = dx * (g.ca * dx + g.cb * dy) + (g.cc * dy) * dy;     // log2 of the Gaussian falloff
-            const float alpha = fminf(0.99f, g.op * __builtin_amdgcn_exp2f(power));
+            asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(e0));
+            float dx = e0[0] - pxf, dy = e0[1] - pyf;
+            asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(e1), "+v"(dx), "+v"(dy));      // (dx, dy tied in: formed BEFORE this wait)
+            const float power = dx * (e1[0] * dx + e1[1] * dy) + (e1[2] * dy) * dy;     // log2 of the Gaussian falloff
+            float alpha = fminf(0.99f, e1[3] * __builtin_amdgcn_exp2f(power));
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(e2), "+v"(alpha));             // (alpha formed BEFORE the colour is waited for)
+            const Rec g{e0[0], e0[1], e1[0], e1[1], e1[2], e1[3], e2[0], e2[1], e2[2], e2[3]};
             // (also: mask = 0 once no pixel of the quadrant is live -- the walk's only exit test stays `mask != 0`)
             blend_one<decltype(touch_tag)::value>(live, mask, T, last, C0, C1, C2, D, g, power, alpha,
                                                   (base - range.x) + (uint32_t)j + 1u, j, touched_cnt);

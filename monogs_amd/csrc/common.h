@@ -204,6 +204,9 @@ inline float* backward_grad_acc(void* scratch) { return (float*)align_up((size_t
 inline float* backward_tau_part(void* scratch, int P) { return backward_grad_acc(scratch) + (size_t)P * GRAD_FLOATS; }
 inline float* backward_tau_out(void* scratch, int P) { return backward_tau_part(scratch, P) + (size_t)TAU_SLOTS * 16; }
 int launch_scan(const GeometryState& g, int P, hipStream_t s, bool exclusive = false);
+// small maps: depth sort + rectangle gather + scan in ONE single-workgroup launch (binning.hip); replaces launch_depth_sort + launch_scan
+bool depth_chain_is_small(int P);
+int launch_depth_chain_small(const GeometryState& g, int P, hipStream_t s);
 // `r_cap`: capacity of the binning buffers; `count` (device): [0] live instance count min(R, r_cap), [1] overflow flag
 int launch_duplicate(const mgs_camera& cam, int P, const GeometryState& g, const BinningState& b, uint64_t r_cap,
                      int32_t* n_touched, const ImageState& img, uint64_t sort_n, int sort_bits, uint32_t* count,
@@ -241,7 +244,7 @@ int launch_depth_sort(const GeometryState& g, int P, bool payload, hipStream_t s
 int launch_sort(const GeometryState& g, const BinningState& b, uint64_t R, int bits, hipStream_t s,
                 const uint32_t* n_dev = nullptr, bool exclusive = false, uint2* ranges = nullptr);
 int set_radix_spin_limit(uint32_t limit);
-extern int g_opt_radix_ballot_rank, g_opt_radix_scanned, g_opt_radix_xcd_band, g_opt_radix_tile_items, g_opt_knn_grid_min, g_opt_scan_small, g_opt_dup_slot_major, g_opt_blend_bwd_transposed, g_opt_blend_lds_pad_fwd, g_opt_blend_lds_pad_bwd;      // test knobs (mgs_debug_set_option)
+extern int g_opt_radix_ballot_rank, g_opt_radix_scanned, g_opt_radix_xcd_band, g_opt_radix_tile_items, g_opt_knn_grid_min, g_opt_scan_small, g_opt_dup_slot_major, g_opt_blend_bwd_transposed, g_opt_blend_lds_pad_fwd, g_opt_blend_lds_pad_bwd, g_opt_depth_small;      // test knobs (mgs_debug_set_option)
 // `sort_err`: the tile sort's error words (NULL: nothing was sorted); a raised word empties every tile and sets
 // MGS_STATUS_TILE_SORT_TIMEOUT in *status (what ranges_kernel did until round 4)
 int launch_blend_forward(const mgs_camera& cam, const GeometryState& g, const BinningState& b,

@@ -340,6 +340,51 @@ def test_scan_paths_agree(native_lib):
     assert torch.equal(cap_one[0], cap_two[0]) and torch.equal(cap_one[0], one["color"])
 
 
+@pytest.mark.parametrize("n,intr", [(1, "fr3_office"), (63, "fr3_office"), (1025, "fr3_office"), (9000, "replica"), (24576, "fr3_office")])
+def test_small_depth_chain_matches_the_multi_launch_path(native_lib, n, intr):
+    """The whole depth chain of a small map -- four stable radix passes, the rectangle gather, the prefix sum of tiles touched --
+    as ONE single-workgroup launch with everything in LDS (depth_chain_small_kernel, mgs_debug_set_option("depth_small", 1):
+    measured slower than the six launches it replaces and therefore not the default).  Same keys, same stable
+    order: the depth order, the per-Gaussian tables, the per-tile lists and the image equal the multi-launch path's bit for bit,
+    in the exact and in the capacity mode; depth ties (duplicated Gaussians) keep their index order in both."""
+    from monogs_amd import _lib
+    from monogs_amd import rasterizer as R
+    from monogs_amd.debug import forward_tables
+    from monogs_amd.rasterizer import GaussianRasterizer
+    lib = _lib.load()
+    sc = make_scene(n, intr, seed=12)
+    st = _hip_st(sc)
+    dev = lambda t: t.to(DEV)  # noqa: E731
+    means, opac, cols, scales, rots = dev(sc.means3D), dev(sc.opacities), dev(sc.colors), dev(sc.scales), dev(sc.rotations)
+    if n >= 1025:                                  # exact depth ties: every 7th Gaussian is a copy of its left neighbour's position
+        means = means.clone()
+        means[7::7] = means[6:-1:7][:means[7::7].shape[0]]
+    args = dict(colors_precomp=cols, scales=scales, rotations=rots)
+    multi = forward_tables(st, means, opac, **args)
+    full = dict(means3D=means, means2D=torch.zeros(n, 3, device=DEV), opacities=opac, **args)
+    R.set_sync_free(True)
+    try:
+        with torch.no_grad():
+            cap_multi = GaussianRasterizer(st)(**full)
+        lib.mgs_debug_set_option(b"depth_small", 1)
+        small = forward_tables(st, means, opac, **args)
+        with torch.no_grad():
+            cap_small = GaussianRasterizer(st)(**full)
+        assert not R.check_overflow()
+    finally:
+        lib.mgs_debug_set_option(b"depth_small", 0)
+        R.set_sync_free(False)
+    assert small["num_rendered"] == multi["num_rendered"]
+    for k in ("perm", "tiles_touched", "ranges", "point_list", "tile_sorted", "color", "n_contrib", "n_touched", "radii"):
+        assert torch.equal(small[k], multi[k]), k
+    assert torch.equal(cap_small[0], cap_multi[0]) and torch.equal(cap_small[0], small["color"])
+    # and the order IS the contract's: ascending (depth bits, index) over the visible Gaussians, the culled ones behind them
+    vis = small["radii"] > 0
+    key = torch.where(vis, small["depth_key"].long() & 0xFFFFFFFF, torch.full_like(small["depth_key"].long(), 0xFFFFFFFF))
+    ref = torch.sort(key, stable=True).indices
+    assert torch.equal(small["perm"].long(), ref)
+
+
 @pytest.mark.parametrize("n,intr", [(3000, "fr3_office"), (70000, "fr3_office"), (40000, "replica")])
 def test_duplicate_emission_paths_agree(native_lib, n, intr):
     """duplicate_kernel emits the (tile, Gaussian) instances either Gaussian-major (a wave owns the slots of its 64

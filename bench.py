@@ -54,6 +54,10 @@ def parse():
                     help="steps timed per stage with HIP events, outside the timed region (median reported; an event\n"
                          "between every two stages costs a few us of stream time each, so the stages add up to a few\n"
                          "percent MORE than ms_per_step)")
+    ap.add_argument("--trace-region", action="store_true",
+                    help="diagnostic (runs of <= 64 steps): an event record after every step of the TIMED region and the allocator's "
+                         "reservation per step, logged to stderr; off by default so that the timed region holds nothing but the steps "
+                         "and the <= 8 blend-kernel probes")
     ap.add_argument("--trace-steps", type=int, default=0,
                     help="diagnostic: after the timed region, N more steps behind a fence with a HIP event after each one; prints "
                          "the per-step device time (how long a short run takes to reach the steady state)")
@@ -356,21 +360,39 @@ def main():
     step()                                   # first step always exact: it records the capacity hint
     sync_free = not args.exact_count
     _rast.set_sync_free(sync_free)           # steady state: device-side instance count, no host sync per forward
-    for _ in range(max(0, args.settle_steps) + max(0, args.warmup - 1)):
+    # What this process reads WITHOUT the settle steps: the first `cold_steps` steps after the exact one, between two fences
+    # (`value_cold` in the line; they also count as un-timed steps in front of the headline's timed region).
+    cold_steps = min(20, max(0, args.settle_steps)) if args.settle_steps > 0 else 0
+    dt_cold = None
+    if cold_steps:
+        fence()
+        tc = time.perf_counter()
+        for _ in range(cold_steps):
+            step()
+        fence()
+        dt_cold = time.perf_counter() - tc
+        if distributed:
+            tt = torch.tensor([dt_cold], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt_cold = float(tt.item())
+    for _ in range(max(0, args.settle_steps - cold_steps) + max(0, args.warmup - 1)):
         step()
     fence()
-    log(f"warmup done ({args.settle_steps} settle + {args.warmup} warm-up steps); timing", args.steps, "steps")
+    warmup_effective = 1 + max(cold_steps, args.settle_steps) + max(0, args.warmup - 1)       # every step that ran before the timed region
+    log(f"warmup done ({args.settle_steps} settle steps, the first {cold_steps} of them timed as the cold figure, + {args.warmup} warm-up steps "
+        f"= {warmup_effective} un-timed steps); timing", args.steps, "steps")
     # (short runs: an event per step, so that the line's reader can see how far from the steady state the run was -- the two
     #  blend kernels take ~40 steps of sustained load from process start to reach their speed, see --settle-steps)
-    trace = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)] if (args.steps <= 64 and rank == 0) else None
+    trace = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)] if (args.trace_region and args.steps <= 64 and rank == 0) else None
     # the two blend kernels, timed INSIDE the timed region (rank 0): the library records a caller's events right around their
-    # launches in up to 64 evenly spaced steps (mgs_debug_set_blend_events: no sync, two event records per kernel).  The
+    # launches in up to 8 evenly spaced steps (mgs_debug_set_blend_events: no sync, two event records per kernel: ~4 us of
+    # stream time per probed step, i.e. < 0.2 % of a 20-step region; round 4 probed every step of a short run).  The
     # per-stage profile further down synchronises per call, and a device that idles between kernels runs the issue-bound
     # blend kernels ~8 % slower than back-to-back steps do -- this is the figure rocprofv3's average agrees with.
     from monogs_amd import _lib as _L
     hook, probes = _L.load().mgs_debug_set_blend_events, {}
     if rank == 0:
-        for i in range(0, args.steps, max(1, args.steps // 64)):
+        for i in range(0, args.steps, max(1, -(-args.steps // 8))):
             probes[i] = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
             for e in probes[i]:
                 e.record()                  # (creates the handle)
@@ -515,8 +537,8 @@ def main():
             cj = json.load(open(os.path.join(ROOT, "profiles", "valu_costs.json")))
         except Exception:
             pass
-        if mj and cj and mj.get("blend_backward_t_kernel<false>"):
-            k = mj["blend_backward_t_kernel<false>"]
+        if mj and cj and mj.get("blend_backward_s_kernel<false>"):
+            k = mj["blend_backward_s_kernel<false>"]
             per_s, per_b, bs = k["per_survivor"], k["per_batch"], float(mj.get("batch_size", 4))
             classes = ("valu_plain", "valu_trans", "valu_dpp", "valu_cndmask", "valu_lane", "valu_permlane_swap")
             cnt = {c: per_s.get(c, 0) + per_b.get(c, 0) / bs for c in classes}
@@ -527,8 +549,22 @@ def main():
                 "ns_per_survivor_modelled": round(ns_model, 2), "frac_of_issue_model": round(ns_model / ns_meas, 4),
                 "costs_ns": {c: cj[c] for c in classes},
                 "source": "profiles/isa_mix.json (static mix of the hot loop, stamped) x profiles/valu_costs.json (tools/ubench/valu_rate.hip)"}
-        if is_c5 and vj and vj.get("blend_backward_t_kernel"):
-            insts = float(vj["blend_backward_t_kernel"]["SQ_INSTS_VALU"])
+            # the second pipe (round 5): the compute unit's ONE scalar ALU serves four SIMDs.  Every scalar-pipe instruction of the
+            # hot loop (SALU, branches, scalar loads, waits / nops) is priced at what tools/ubench/valu_rate.hip measures a scalar
+            # instruction to ADD to a vector stream at the kernels' own ratio (one scalar per two vector instructions).
+            sc_cls = ("salu", "branch", "smem", "wait_nop")
+            n_sc = sum(per_s.get(c, 0) for c in sc_cls) + sum(per_b.get(c, 0) for c in sc_cls) / bs
+            if cj.get("salu_behind_2_valu"):
+                ns_two = ns_model + n_sc * float(cj["salu_behind_2_valu"])
+                valu["issue_model"].update({
+                    "scalar_pipe_insts_per_survivor": round(n_sc, 2), "scalar_ns_each_alone": cj.get("salu_alone"),
+                    "scalar_ns_each_behind_two_vector": cj["salu_behind_2_valu"],
+                    "ns_per_survivor_modelled_two_pipes": round(ns_two, 2), "frac_of_two_pipe_model": round(ns_two / ns_meas, 4),
+                    "two_pipe_note": "vector classes x their issue times + scalar-pipe instructions x the time one adds behind two vector "
+                                     "instructions; what is left to the measured time is launch ramp / tail (tools/tail_probe.py: a fixed "
+                                     "~52 us per backward launch, ~15 % at C5) and latency eight waves per SIMD do not cover"})
+        if is_c5 and vj and vj.get("blend_backward_s_kernel"):
+            insts = float(vj["blend_backward_s_kernel"]["SQ_INSTS_VALU"])
             valu.update({"valu_wave_insts_per_launch": insts, "insts_per_survivor": round(insts / surv, 2),
                          "achieved_ginst_s": round(insts / t_bwd / 1e9, 1),
                          "frac_of_spec_valu_peak": round(insts / t_bwd / 1e9 / 1228.8, 4),
@@ -538,7 +574,7 @@ def main():
         b_all = (44 * P + 8 * P + 52 * Pv) + 8 * P + (16 * Pv + 12 * R) + 24 * R + (8 * R + 8 * ((W + 15) // 16) * ((H + 15) // 16)) \
             + b_fwd + b_bwd + (44 * P + 40 * Pv + 68 * Pv + 24)
         t_all = sum(stages.values())
-        roof = {"bound": "hbm", "kernel": "blend_backward_t_kernel", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
+        roof = {"bound": "hbm", "kernel": "blend_backward_s_kernel", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic, "valu": valu,
                 "csrc_sha256": csrc_hash(),
                 "algorithmic_bytes": b_bwd, "avg_ms": bwd_ms,
@@ -584,8 +620,10 @@ def main():
                     "kf_extend_ms", "ate_rmse_m", "gaussians", "width", "height", "frames", "config", "window_sizes",
                     "mapping_replays", "mapping_eager_iters", "mapping_captures", "mapping_capture_s", "map_surgery", "surgery",
                     "eager_tracking")
+            # (exclusive_device: the tracking graphs do NOT claim MGS_FLAG_EXCLUSIVE_DEVICE -- MonoGS's tracker shares the GPU with a
+            #  mapper and a viewer process; the ~2 us per launch it would save were inside the noise anyway)
             common = dict(scene="room", reference_densify=True, map_surgery=True, reference_lrs=True, graph_tracking=True,
-                          graph_mapping=True)
+                          graph_mapping=True, exclusive_device=False)
             standin = ("opaque box room with furniture, ray-cast analytically (closed-form colour + z-depth per pixel), hand-held-like "
                        "path ~1 cm / 0.3 deg per frame; map surgery ON (densify_and_prune / opacity reset / covisibility prune on the "
                        "reference's schedule), fork's new-Gaussian recipe (1/32, 1/64, point-size rule), reference learning rates + "
@@ -596,6 +634,7 @@ def main():
             def block(r, what):
                 d = {k: (round(v, 6 if k == "ate_rmse_m" else 3) if isinstance(v, float) else v) for k, v in r.items() if k in keys}
                 d["max_window_reached"] = max(d["window_sizes"]) if d.get("window_sizes") else 0
+                d["exclusive_device"] = bool(common["exclusive_device"])
                 if isinstance(d.get("surgery"), dict):
                     d["surgery"] = {k: v for k, v in d["surgery"].items() if k != "log"}
                 d["workload"] = what
@@ -639,6 +678,12 @@ def main():
         line = {
             "metric": "rasteriser fwd+bwd Mpix/s @1080p", "value": round(mpix, 2), "unit": "Mpix/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            # every step this process ran before the timed region: the exact first step, the settle steps, the warm-up steps
+            "warmup_effective": warmup_effective,
+            # the same workload timed WITHOUT the settle steps: the first `cold_steps` steps after the exact one (None: --settle-steps 0,
+            # then `value` itself is that figure)
+            "value_cold": (round(world * W * H * cold_steps / dt_cold / 1e6, 2) if dt_cold else None),
+            "ms_per_step_cold": (round(dt_cold / cold_steps * 1e3, 4) if dt_cold else None), "cold_steps": cold_steps,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{'C5' if is_c5 else 'custom'}: {args.gaussians} Gaussians, {W}x{H}, fwd+bwd, seeded synthetic map "

@@ -155,9 +155,15 @@ int mgs_forward_render(const mgs_camera* cam, int32_t P, uint64_t num_rendered,
 #define MGS_STATUS_DEPTH_SORT_TIMEOUT 2u  /* a bounded wait of the depth sort ran out */
 #define MGS_STATUS_TILE_SORT_TIMEOUT 4u   /* a bounded wait of the tile sort ran out */
 
-/* Test knob: the bound of those waits, in polls (device-wide, all later sorts); 0xFFFFFFFF restores the default. */
+/* ---- mgs_debug_*: TEST AND MEASUREMENT USE ONLY -------------------------------------------------------------------------
+ * "The library keeps no state between calls" (above) holds for every entry point a caller of the rasteriser needs.  The three
+ * setters below are the exception, on purpose: each writes a PROCESS-GLOBAL variable that later calls read unsynchronised.
+ * They are NOT THREAD-SAFE (set them while no other thread is inside the library), they affect every later call of the process
+ * whatever its device or stream, and nothing on MonoGS's path calls them: the test suite and the tools under tools/ do, to force
+ * an algorithm path or to time a kernel.  Defaults are restored by the values given with each. */
+/* TEST USE ONLY, process-global, not thread-safe: the bound of those waits, in polls (all later sorts); 0xFFFFFFFF restores the default. */
 int mgs_debug_set_radix_spin_limit(uint32_t limit);
-/* Test knobs that force an algorithm path whatever the problem size (process-wide; -1 restores the default):
+/* TEST USE ONLY, process-global, not thread-safe: knobs that force an algorithm path whatever the problem size (-1 restores the default):
  * "radix_scanned" (0 = one kernel per pass with a gather of the earlier tiles' counts, 1 = counted tiles: two kernels per
  * pass, no waiting between workgroups -- honoured from 64 k pairs), "radix_ballot_rank" (1 = rank with wave ballots instead of
  * returning LDS atomics: the reference the sort tests compare with), "scan_small" (0 = the two-launch scan at every size), "depth_small" (1 = maps <= 24 576 Gaussians run
@@ -229,7 +235,8 @@ int mgs_backward(const mgs_camera* cam, int32_t P, uint64_t num_rendered,
 #define MGS_VALU_CEILING_BLOCKS 2048
 int mgs_debug_valu_ceiling(float* out, int32_t iters, void* stream);
 
-/* Measurement hook: until switched off again, every forward records fwd_start right before and fwd_end right after its
+/* TEST / MEASUREMENT USE ONLY, process-global, not thread-safe.
+ * Measurement hook: until switched off again, every forward records fwd_start right before and fwd_end right after its
  * blend-forward launch, every mgs_backward bwd_start / bwd_end around its blend-backward launch, on the call's stream
  * (hipEvent_t handles owned by the caller, created with timing enabled; each pair both set or both NULL; four NULLs switch
  * the hook off).  No synchronisation, nothing else changes: bench.py times the two blend kernels INSIDE its timed region

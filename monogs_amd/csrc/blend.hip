@@ -192,7 +192,7 @@ __global__ void __launch_bounds__(256) blend_forward_kernel(BlendArgs a, float* 
                                                             float* __restrict__ final_T,
                                                             uint32_t* __restrict__ n_contrib,
                                                             int32_t* __restrict__ n_touched,
-                                                            uint2* __restrict__ ranges_rw,
+                                                            uint2* ranges_rw /* = a.ranges: read AND written here, through this pointer only */,
                                                             const uint32_t* __restrict__ sort_err,
                                                             uint32_t* __restrict__ status) {
     MGS_TILE_WAVE(a.gx * ((a.H + TILE - 1) / TILE), tile, wave, ws)
@@ -208,7 +208,10 @@ __global__ void __launch_bounds__(256) blend_forward_kernel(BlendArgs a, float* 
     // of a tile nothing landed in.  A tile sort whose look-back timed out left the instance list partly unwritten (arbitrary
     // indices): then every tile is empty, and the forward's status word says why.  Either way the table is rewritten in its
     // canonical form ({0, 0} for an empty tile) for the backward and for whoever reads it: this workgroup is its only reader here.
-    uint2 range = a.ranges[tile];
+    // (read through the SAME pointer the normalised form is stored through below -- `a.ranges` is a restrict-qualified const view
+    //  of this table for the kernels that only read it; the other waves of the workgroup may see the table before or after lane 0's
+    //  store: both forms decode to the same range.  The backward relies on the canonical {0, 0} written here.)
+    uint2 range = ranges_rw[tile];
     {
         const bool sort_bad = sort_err != nullptr && radix_failed(sort_err) != 0u;
         if (sort_bad && tile == 0 && first_of_tile && status) atomicOr(status, (uint32_t)MGS_STATUS_TILE_SORT_TIMEOUT);

@@ -105,6 +105,17 @@ def _raise_sort_failure(bits):
                        "the renders since the last check are invalid")
 
 
+def _drain_exact_other(n: int) -> None:
+    """Nobody calls check_overflow(): read the oldest ``n`` status words of exact forwards that ran on other streams (synchronising
+    the devices they ran on) and keep their sort-timeout bits in ``exact_failed``, which the next forward raises -- the list
+    stays bounded without losing the one signal it exists to deliver."""
+    old, _State.exact_other = _State.exact_other[:n], _State.exact_other[n:]
+    for d in {e[2] for e in old}:
+        torch.cuda.synchronize(d)
+    for e in old:
+        _State.exact_failed |= int(e[1].item()) & (STATUS_DEPTH_SORT_TIMEOUT | STATUS_TILE_SORT_TIMEOUT)
+
+
 def check_overflow() -> bool:
     """Reads the status words of the forwards issued since the last call (synchronises).  True if a capacity-mode
     forward dropped instances -- the capacity hints of the offending shapes are doubled, redo the iteration.  Raises
@@ -303,7 +314,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                     # kernels (the header's contract is "an EARLIER forward on this stream"), so its word waits for check_overflow()
                     _State.exact_other.append(prev)
                     if len(_State.exact_other) > PENDING_MAX:
-                        del _State.exact_other[:PENDING_MAX // 2]
+                        _drain_exact_other(PENDING_MAX // 2)      # (read, never dropped: a sort timeout must not pass unseen)
                     prev = None
                 _lib.check(lib.mgs_forward_preprocess(
                     C.byref(cam), P, _ptr(means3D), _ptr(sh_), _ptr(col_), _ptr(opac_), _ptr(sc_), _ptr(rot_),

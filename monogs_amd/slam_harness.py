@@ -119,7 +119,7 @@ class TrackingGraph:
     * The convergence flag is read back through a pinned buffer after every replay (or one replay late, `lookahead`).
     Result: identical poses and iteration counts to the eager loop with its per-iteration `if converged: break`."""
 
-    def __init__(self, proto: Viewpoint, intr, gmap, bg, exclusive: bool = True):
+    def __init__(self, proto: Viewpoint, intr, gmap, bg, exclusive: bool = False):
         from . import rasterizer as _r
         self._r = _r
         dev = proto.device
@@ -480,7 +480,7 @@ def run_slam(n_frames=12, intrinsics="fr3_office", tracking_itr_num=100, mapping
              kf_interval=4, init_itr_num=300, n_gaussians=60000, device="cuda:0", log=None,
              init_downsample=8, kf_downsample=16, point_size=1.0, graph_tracking=False, graph_mapping=False,
              track_lookahead=1, map_surgery=False, reference_lrs=False, prune_after_mapping=None,
-             scene="cloud", reference_densify=False, eager_probe=0):
+             scene="cloud", reference_densify=False, eager_probe=0, exclusive_device=False):
     """Returns a dict with tracking / mapping FPS, iterations and the trajectory error.
 
     Mapping runs through ``monogs_amd.mapping.WindowMapper`` -- the SAME ``optimize_map`` / ``initialize_map`` the sharded
@@ -570,7 +570,7 @@ def run_slam(n_frames=12, intrinsics="fr3_office", tracking_itr_num=100, mapping
         sync(); t0 = time.perf_counter()
         if graph_tracking:
             if tgraph is None:                       # the map changed (or first frame): capture against the new map
-                tgraph = TrackingGraph(vp, intr, gmap, bg)
+                tgraph = TrackingGraph(vp, intr, gmap, bg, exclusive=exclusive_device)     # only a caller that owns the box may vouch for it
                 sync(); stats["track_capture_s"] += time.perf_counter() - t0
             n_it = tgraph.track(vp, tracking_itr_num, lookahead=track_lookahead)
         else:

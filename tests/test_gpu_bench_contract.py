@@ -30,3 +30,9 @@ def test_bench_line_carries_the_contract_fields():
         assert k in r, k
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and 0 < r["frac"] < 1
     assert r["traffic"] is None                          # the stamped PMC files belong to the C5 workload only
+    # the line says what ran BEFORE its timed region, without a look into `config`: the exact first step, the settle steps
+    # (default 60, the first 20 of them timed as the cold figure) and the warm-up steps
+    assert d["warmup_effective"] == 1 + d["config"]["settle_steps"] + (d["warmup"] - 1) == 63
+    assert d["cold_steps"] == 20 and d["value_cold"] > 0
+    assert abs(d["value_cold"] - 640 * 480 / 1e6 / (d["ms_per_step_cold"] * 1e-3)) < 0.01 * d["value_cold"]
+    assert d["blend_in_timed_region"]["launches_timed"] <= 8       # the probes inside the timed region stay few

@@ -132,11 +132,23 @@ def test_tracking_and_mapping_with_the_reference_map_surgery(native_lib):
     the fork's new-Gaussian recipe (1/32 and 1/64 of the pixels, scale^2 = dist2 x min(0.05, 0.01 x median depth)) and its
     learning rates -- on a sequence of OPAQUE surfaces (a ray-cast room), hipGraph-replayed with a re-capture after every
     map-size change.  The map must neither collapse nor explode, both halves of the surgery must fire, and tracking must
-    keep converging against the maps the surgery leaves behind."""
+    keep converging against the maps the surgery leaves behind.
+
+    How good "keeps converging" has to be is DERIVED, not read off a run (round 4 widened fitted bars after a failure):
+      * against the same 13 frames run EAGERLY (no hipGraph, exact instance counts: the loop an unmodified caller runs): the
+        replayed run's worst frame and its ATE may be at most twice the eager run's (+ 1.5 mm, 15 % of the ~1 cm the camera
+        moves per frame: two runs of one sequence differ by the order of their float atomics, and the surgery's thresholds
+        turn that into slightly different maps; measured in round 5: 9.9 / 3.0 mm replayed against 11.0 / 3.3 mm eager);
+      * against the same frames with the surgery switched OFF: pruning may cost accuracy, but not more than a factor of two
+        (+ 1.5 mm) in ATE -- the reference prunes on every keyframe and still tracks (measured: 3.0 against 1.3 mm).
+    The worst frame is the one right behind a covisibility prune: it drops every Gaussian that at most three of the window's
+    keyframes touch with T (1 - alpha) > 0.5 -- about two thirds of the map at once, mostly clones sitting behind their originals,
+    but also the only Gaussians of regions that just came into view -- so that frame is tracked against a map with holes, where the
+    tracking loss's opacity weighting leaves fewer pixels to hold the pose."""
     from monogs_amd.slam_harness import run_slam
-    r = run_slam(n_frames=13, intrinsics="fr3_office", tracking_itr_num=100, mapping_itr_num=150, window_size=5, kf_interval=2,
-                 init_itr_num=1050, scene="room", reference_densify=True, map_surgery=True, reference_lrs=True,
-                 graph_tracking=True, graph_mapping=True)
+    cfg = dict(n_frames=13, intrinsics="fr3_office", tracking_itr_num=100, mapping_itr_num=150, window_size=5, kf_interval=2,
+               init_itr_num=1050, scene="room", reference_densify=True, reference_lrs=True)
+    r = run_slam(map_surgery=True, graph_tracking=True, graph_mapping=True, **cfg)
     s = r["surgery"]
     sizes = s["gaussians_after_keyframe"]
     print("map size after each keyframe:", sizes, {k: v for k, v in s.items() if k not in ("log", "gaussians_after_keyframe")})
@@ -147,9 +159,21 @@ def test_tracking_and_mapping_with_the_reference_map_surgery(native_lib):
     assert s["covisibility_prunes"] >= 2                           # the window of five is full from the fifth keyframe on
     assert min(sizes) > 4000 and max(sizes) < 150000, sizes        # 9 600 initial Gaussians: no collapse, no explosion
     assert r["mapping_captures"] >= 6 and r["mapping_replays"] > 1500
-    # tracking after surgery: every frame converges before the iteration cap and lands within centimetres (the covisibility
-    # prune takes two thirds of the map away at once: the frames right behind it are the worst, ~1 cm was observed)
-    assert all(1 < n < 100 for _, n in r["track_iters_per_frame"]), r["track_iters_per_frame"]
-    assert max(r["position_error_m"]) < 2.5e-2 and r["ate_rmse_m"] < 6e-3, (r["ate_rmse_m"], r["position_error_m"])
+    assert all(1 < n < 100 for _, n in r["track_iters_per_frame"]), r["track_iters_per_frame"]     # every frame converges before the cap
     first, last = r["map_loss"][0]
     assert last < 0.1 * first                                      # map initialisation from sparse dots to a covered image
+
+    eager = run_slam(map_surgery=True, graph_tracking=False, graph_mapping=False, **cfg)
+    # (the surgery-free reference maps eagerly: without the re-captures that surgery forces every <= 150 iterations, 1 049 replays
+    #  of ONE captured initialisation iteration outgrow the instance capacity recorded at capture time -- the harness reports that
+    #  as an error rather than dropping instances; this run is an accuracy reference, its speed does not matter)
+    off = run_slam(map_surgery=False, graph_tracking=True, graph_mapping=False, **cfg)
+    worst = lambda x: max(x["position_error_m"])  # noqa: E731
+    print(f"replayed + surgery: worst frame {worst(r) * 1e3:.2f} mm, ATE {r['ate_rmse_m'] * 1e3:.2f} mm | eager + surgery: "
+          f"{worst(eager) * 1e3:.2f} / {eager['ate_rmse_m'] * 1e3:.2f} mm | no surgery: {worst(off) * 1e3:.2f} / "
+          f"{off['ate_rmse_m'] * 1e3:.2f} mm")
+    assert eager["surgery"]["covisibility_prunes"] >= 2
+    slack = 1.5e-3
+    assert worst(r) <= 2.0 * worst(eager) + slack and r["ate_rmse_m"] <= 2.0 * eager["ate_rmse_m"] + slack
+    assert r["ate_rmse_m"] <= 2.0 * off["ate_rmse_m"] + slack
+    assert worst(eager) < 0.05 and worst(off) < 0.05             # (sanity of the references themselves: centimetres, not decimetres)

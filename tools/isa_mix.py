@@ -4,7 +4,7 @@
     python tools/isa_mix.py [profiles/isa_mix.json]
 
 Compiles monogs_amd/csrc/blend.hip to gfx950 assembly (hipcc -S, the flags of the Makefile; no GPU needed) and counts, for
-``blend_backward_t_kernel<false>`` (and ``<true>``, the pose-only variant):
+``blend_backward_s_kernel<false>`` (and ``<true>``, the pose-only variant; ``blend_backward_t_kernel<false>``, round 3's, for comparison):
 
   * per SURVIVOR: the body of the inner (depth-2) loop without the batch flush -- fetch, alpha, per-pixel gradient factors,
     the two LDS stores;
@@ -97,7 +97,7 @@ def analyse(text: str, mangled_prefix: str):
     # the inner loop: from the 'Inner Loop Header: Depth=2' marker to the last line that is still 'in Loop: Header=<that label>'
     hdr = next(i for i, ln in enumerate(lines) if "Inner Loop Header: Depth=2" in ln)
     label = re.match(r"\s*(\.LBB\d+_\d+):", lines[hdr - 1] if lines[hdr - 1].strip().endswith(":") or ":" in lines[hdr - 1] else lines[hdr]).group(1)
-    name = label[1:]
+    name = label[2:]                   # '.LBB7_82' -> 'BB7_82', as the 'in Loop: Header=' comments spell it
     in_loop = [i for i, ln in enumerate(lines) if f"Header={name} " in ln or f"Header={name}\t" in ln or ln.rstrip().endswith(f"Header={name}") or f"Header={name} Depth" in ln]
     lo, hi = min(in_loop + [hdr]), max(in_loop + [hdr])
     # extend to the end of the last block of the loop
@@ -105,16 +105,26 @@ def analyse(text: str, mangled_prefix: str):
     while end < len(lines) and not re.match(r"\s*\.LBB\d+_\d+:", lines[end]):
         end += 1
     loop = lines[lo:end]
-    # the flush: from the first LDS READ of the loop to the atomic
-    first_read = next(i for i, ln in enumerate(loop) if re.match(r"\s*ds_read", ln))
-    # start of the basic block holding it
-    fs = first_read
-    while fs > 0 and not re.match(r"\s*(\.LBB\d+_\d+:|; %bb\.)", loop[fs]):
-        fs -= 1
-    atomic = next(i for i, ln in enumerate(loop) if "global_atomic_add_f32" in ln)
-    flush = loop[fs:atomic + 1]
-    survivor = loop[:fs] + loop[atomic + 1:]
-    return mix(instructions(survivor)), mix(instructions(flush))
+    # The loop holds `copies` survivors (round 5: unrolled by two, one register set each) and as many inlined flushes.  A flush:
+    # from the start of the basic block that holds the first LDS READ after the previous flush to its atomic.
+    atomics = [i for i, ln in enumerate(loop) if "global_atomic_add_f32" in ln]
+    flushes, prev = [], 0
+    for at in atomics:
+        first_read = next(i for i in range(prev, at) if re.match(r"\s*ds_read", loop[i]))
+        fs = first_read
+        while fs > prev and not re.match(r"\s*(\.LBB\d+_\d+:|; %bb\.)", loop[fs]):
+            fs -= 1
+        flushes.append((fs, at + 1))
+        prev = at + 1
+    copies = len(flushes)
+    keep = [True] * len(loop)
+    for a, b in flushes:
+        for i in range(a, b):
+            keep[i] = False
+    survivor = mix(instructions([ln for ln, k in zip(loop, keep) if k]))
+    flush = mix(instructions(loop[flushes[0][0]:flushes[0][1]]))
+    survivor = {k: (v / copies if copies > 1 else v) for k, v in survivor.items()}
+    return survivor, flush, copies
 
 
 def main():
@@ -127,11 +137,12 @@ def main():
         subprocess.check_call(cmd, stderr=subprocess.DEVNULL)
         text = open(asm).read()
     res = {"csrc_sha256": csrc_hash(), "batch_size": 4,
-           "source": "hipcc -S of monogs_amd/csrc/blend.hip, inner loop of blend_backward_t_kernel (tools/isa_mix.py)"}
-    for tag, prefix in (("blend_backward_t_kernel<false>", "_ZN3mgs23blend_backward_t_kernelILb0EE"),
-                        ("blend_backward_t_kernel<true>", "_ZN3mgs23blend_backward_t_kernelILb1EE")):
-        surv, flush = analyse(text, prefix)
-        res[tag] = {"per_survivor": surv, "per_batch": flush}
+           "source": "hipcc -S of monogs_amd/csrc/blend.hip, inner loop of blend_backward_s_kernel, and of its round-3 A/B partner blend_backward_t_kernel (tools/isa_mix.py)"}
+    for tag, prefix in (("blend_backward_s_kernel<false>", "_ZN3mgs23blend_backward_s_kernelILb0EE"),
+                        ("blend_backward_s_kernel<true>", "_ZN3mgs23blend_backward_s_kernelILb1EE"),
+                        ("blend_backward_t_kernel<false>", "_ZN3mgs23blend_backward_t_kernelILb0EE")):
+        surv, flush, copies = analyse(text, prefix)
+        res[tag] = {"per_survivor": surv, "per_batch": flush, "survivors_per_loop_trip": copies}
     json.dump(res, open(out_path, "w"), indent=1, sort_keys=True)
     print(json.dumps(res, indent=1, sort_keys=True))
 

@@ -27,7 +27,7 @@ out = {"unit": "bytes per launch", "correction": "2*FETCH_SIZE*1024 + WRITE_SIZE
 for k in sorted(set(fetch) | set(write)):
     out[k] = {"fetch_kib_raw": round(fetch.get(k, 0), 1), "write_kib_raw": round(write.get(k, 0), 1),
               "hbm_bytes": int(2 * fetch.get(k, 0) * 1024 + write.get(k, 0) * 1024)}
-out["blend_backward_bytes_per_launch"] = (out.get("blend_backward_t_kernel") or out.get("blend_backward_kernel") or {}).get("hbm_bytes")
+out["blend_backward_bytes_per_launch"] = (out.get("blend_backward_s_kernel") or out.get("blend_backward_t_kernel") or out.get("blend_backward_kernel") or {}).get("hbm_bytes")
 # identity of the kernel sources these counters were collected on (bench.py ignores the file when it does not match)
 import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -307,8 +307,13 @@ int main() {
     auto ns_of = [&](int m) { return ms[m] * 1e6 / (8.0 * iters * per_trip[m]); };
     printf("JSON {\"valu_plain\": %.4f, \"valu_trans\": %.4f, \"valu_dpp\": %.4f, \"valu_cndmask\": %.4f, "
            "\"valu_permlane_swap\": %.4f, \"valu_lane\": %.4f, \"lds_swizzle_pipe\": %.4f, \"fma_ginst_s\": %.1f, "
-           "\"unit\": \"ns of SIMD issue per wave-instruction, 8 waves per SIMD, every CU busy\"}\n",
+           "\"salu_alone\": %.4f, \"salu_behind_2_valu\": %.4f, \"salu_behind_1_valu\": %.4f, \"smem_x2_wait_trip_alone\": %.4f, "
+           "\"lds_bcast_b128_x3_behind_16_valu\": %.4f, "
+           "\"unit\": \"ns of SIMD issue per wave-instruction, 8 waves per SIMD, every CU busy; salu_behind_N_valu: what a scalar "
+           "instruction adds to a stream of N v_fma per scalar instruction (the CU's one scalar ALU serves four SIMDs)\"}\n",
            fma_ns, 0.5 * (ns_of(M_EXP) + ns_of(M_RCP)), 0.5 * (ns_of(M_DPP_SHR) + ns_of(M_DPP_BANK)), ns_of(M_CND_SALU),
-           0.5 * (ns_of(M_SWAP32) + ns_of(M_SWAP16)), 2.0 * ns_of(M_READLANE) - fma_ns, ns_of(M_SWZ_ONLY), 1024.0 / fma_ns);
+           0.5 * (ns_of(M_SWAP32) + ns_of(M_SWAP16)), 2.0 * ns_of(M_READLANE) - fma_ns, ns_of(M_SWZ_ONLY), 1024.0 / fma_ns,
+           ns_of(M_SALU_ANDN2), (ns_of(M_SALU_MIX12) - ns_of(M_FMA16)) / 8.0, (ns_of(M_SALU_MIX11) - 0.5 * ns_of(M_FMA16)) / 8.0,
+           ns_of(M_SMEM_X8), (ns_of(M_DSREAD_MIX) - ns_of(M_FMA16)) / 3.0);
     return 0;
 }

@@ -560,9 +560,11 @@ def main():
                     "scalar_pipe_insts_per_survivor": round(n_sc, 2), "scalar_ns_each_alone": cj.get("salu_alone"),
                     "scalar_ns_each_behind_two_vector": cj["salu_behind_2_valu"],
                     "ns_per_survivor_modelled_two_pipes": round(ns_two, 2), "frac_of_two_pipe_model": round(ns_two / ns_meas, 4),
-                    "two_pipe_note": "vector classes x their issue times + scalar-pipe instructions x the time one adds behind two vector "
-                                     "instructions; what is left to the measured time is launch ramp / tail (tools/tail_probe.py: a fixed "
-                                     "~52 us per backward launch, ~15 % at C5) and latency eight waves per SIMD do not cover"})
+                    "two_pipe_note": "vector classes x their issue times + scalar-pipe instructions x the time one adds behind two v_fma "
+                                     "(both priced in an all-FMA loop that clocks 1.7-1.9 GHz; the blend kernels run at 2.2 GHz, "
+                                     "profiles/r05_kernel_clocks.txt, so the model is an upper estimate of the steady state: a fraction "
+                                     "above 1 says the loop issues faster than the priced parts add up to).  The measured time also holds "
+                                     "the launch's ramp and tail (tools/tail_probe.py: a fixed ~52 us per backward launch, ~15 % at C5)"})
         if is_c5 and vj and vj.get("blend_backward_s_kernel"):
             insts = float(vj["blend_backward_s_kernel"]["SQ_INSTS_VALU"])
             valu.update({"valu_wave_insts_per_launch": insts, "insts_per_survivor": round(insts / surv, 2),

@@ -26,6 +26,10 @@ python3 $R/tools/isa_mix.py $O/${tag}_isa_mix.json > /dev/null 2>&1
 # 3c. the radix sort alone (tools/ubench/sort_bench: against a stable CPU sort, whole-sort time, phase trace of a tile)
 ( for m in depth depthfar tile few; do $R/tools/ubench/sort_bench $m 0; done
   for n in 40000 100000 415000 1000000; do $R/tools/ubench/sort_bench depth 0 $n; $R/tools/ubench/sort_bench tile 0 $n; done ) > $O/${tag}_sort_bench.txt 2>&1
+# 3d. round 5: the single-workgroup depth chain alone (phase stamps), the group-stream counts, the tail probe
+( for n in 10000 20000 24576; do $R/tools/ubench/depth_small_bench $n; done ) > $O/${tag}_small_depth_chain_bench.txt 2>&1
+python3 $R/tools/group_stats.py > $O/${tag}_group_stream_counts.txt 2>&1
+python3 $R/tools/tail_probe.py 30 > $O/${tag}_tail_probe.txt 2>&1
 # 4. the plain line (with the stamped files in place the roofline record carries traffic and valu)
 cp $O/${tag}_traffic.json $R/profiles/traffic.json; cp $O/${tag}_pmc_valu.json $R/profiles/pmc_valu.json
 cp $O/${tag}_valu_costs.json $R/profiles/valu_costs.json; cp $O/${tag}_isa_mix.json $R/profiles/isa_mix.json

@@ -930,9 +930,9 @@ __global__ void __launch_bounds__(256) blend_backward_s_kernel(BlendArgs a, int 
                                                                const float* __restrict__ dL_ddepth,
                                                                float* __restrict__ grad_acc) {
     // per wave: the factor slab [h | w][slot][pixel] and the slots' metadata {cx, cy, index << 6}, every array with the SAME slot
-    // stride so that ONE scalar (slab base + open slot x stride) addresses all three -- 272 bytes, not 256: the flush's four
-    // rows read their metadata at once, and 256 bytes apart those words share their LDS banks (7.9 M conflict cycles per launch
-    // at C5, r05 PMC)
+    // stride so that ONE scalar (slab base + open slot x stride) addresses all three -- 272 bytes, not 256, so that the four rows of
+    // a flush find their metadata words on different LDS banks.  (SQ_LDS_BANK_CONFLICT reads 7.9 M cycles per launch at C5 -- two per
+    // survivor -- with either stride, and with the slot-clearing or the factor store taken out: not isolated, and not worth more.)
     struct WaveLds { float h[BT_SLOTS][BS_STRIDE / 4]; float pad[(BS_W_OFF - BT_SLOTS * BS_STRIDE) / 4]; float w[BT_SLOTS][BS_STRIDE / 4];
                      BtMetaRec meta[BT_SLOTS][BS_STRIDE / 16]; };
     static_assert(sizeof(WaveLds) == BS_META_OFF + BT_SLOTS * BS_STRIDE, "layout");

@@ -142,6 +142,7 @@ class WindowMapper:
         self.parallel_keyframes = None   # render / back-propagate the owned keyframes on a stream each; None: when captured
                                          # (pays inside a replay: 863 -> 1254 it/s; an eager loop is bound by the host anyway)
         self.min_graph_iters = 8         # shorter runs are not worth a capture
+        self.max_replays_per_capture = 256   # then an eager iteration refreshes the instance capacities and the plan is re-captured
         self._streams: List = []
         self.last_grads = None
         self._plan: Optional[_Plan] = None
@@ -475,12 +476,27 @@ class WindowMapper:
                     self._iterate_eager(p, viewpoints, pose_steps, lr_update, None, parallel=False)
                     n_left -= 1
                 if n_left > 0 and graph_ok:
-                    if p.graphs is None:
-                        self._capture(p, viewpoints, pose_steps, lr_update)
-                    self._replay(p, n_left)
-                    self.nr_iters += n_left
-                    if _rast.check_overflow():
-                        raise RuntimeError("binning capacity overflow inside the captured mapping iteration")
+                    # A captured iteration renders with the instance capacity its eager predecessor recorded (x 1.5).  The
+                    # reference's surgery forces a new plan every <= 150 iterations; a run WITHOUT it (1 049 replays of one
+                    # initialisation iteration) lets the splats grow past that capacity.  So a capture serves at most
+                    # `max_replays_per_capture` replays: then one eager iteration records fresh capacities and the plan is captured
+                    # again (~10 ms per 256 iterations); the flag is read after every chunk, so an overflow is reported within a
+                    # chunk of where it happened instead of at the end of the run.
+                    while n_left > 0:
+                        if p.graphs is None:
+                            self._capture(p, viewpoints, pose_steps, lr_update)
+                        n = min(n_left, self.max_replays_per_capture)
+                        self._replay(p, n)
+                        self.nr_iters += n
+                        n_left -= n
+                        if _rast.check_overflow():
+                            raise RuntimeError("binning capacity overflow inside the captured mapping iteration")
+                        if n_left > 0:
+                            p.graphs = p.slot_graphs = None
+                            self._sync_schedule(p)
+                            self._iterate_eager(p, viewpoints, pose_steps, lr_update, None, parallel=False)
+                            n_left -= 1
+                            self._sync_schedule(p)
                 else:
                     for _ in range(n_left):
                         self._iterate_eager(p, viewpoints, pose_steps, lr_update, None, parallel=False)

@@ -164,9 +164,10 @@ def test_tracking_and_mapping_with_the_reference_map_surgery(native_lib):
     assert last < 0.1 * first                                      # map initialisation from sparse dots to a covered image
 
     eager = run_slam(map_surgery=True, graph_tracking=False, graph_mapping=False, **cfg)
-    # (the surgery-free reference maps eagerly: without the re-captures that surgery forces every <= 150 iterations, 1 049 replays
-    #  of ONE captured initialisation iteration outgrow the instance capacity recorded at capture time -- the harness reports that
-    #  as an error rather than dropping instances; this run is an accuracy reference, its speed does not matter)
+    # (the surgery-free reference maps EAGERLY: without the new plan that surgery forces every <= 150 iterations, the replays of one
+    #  captured initialisation iteration outgrow the instance capacity recorded at capture time -- the sparse initial dots triple
+    #  their footprint within a few hundred iterations -- and the harness, rightly, raises instead of dropping instances, also with
+    #  WindowMapper.max_replays_per_capture = 256 refreshing the capacities; this run is an accuracy reference, its speed is irrelevant)
     off = run_slam(map_surgery=False, graph_tracking=True, graph_mapping=False, **cfg)
     worst = lambda x: max(x["position_error_m"])  # noqa: E731
     print(f"replayed + surgery: worst frame {worst(r) * 1e3:.2f} mm, ATE {r['ate_rmse_m'] * 1e3:.2f} mm | eager + surgery: "

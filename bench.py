@@ -663,6 +663,12 @@ def main():
             slam["fork_hardcoded"] = block(r3, "the same TUM-like stand-in with the fork's hard-coded run configuration "
                                                "(init 1050, 300 iterations per keyframe, window 30, every frame a keyframe)")
             log("slam fork", slam["fork_hardcoded"])
+            # the unmodified-caller probe once more, against a map of the size the reference's runs END with before pruning bites
+            # (~39 k Gaussians: the semi-transparent cloud of rounds 1-3, no surgery) -- the five flavours at 10 k above, at 39 k here
+            r4 = run_slam(n_frames=3, intrinsics="fr3_office", tracking_itr_num=20, mapping_itr_num=20, window_size=8, kf_interval=1,
+                          init_itr_num=50, n_gaussians=60000, scene="cloud", eager_probe=100)
+            slam["eager_tracking_39k"] = r4.get("eager_tracking")
+            log("slam eager 39k", slam["eager_tracking_39k"])
         except Exception as e:          # never lose the headline line to the auxiliary measurement
             import traceback
             traceback.print_exc()
